@@ -1,0 +1,361 @@
+// Tape interpreter kernels for gfx950: one lane per input vector, the tape is
+// wave-uniform (fetched with scalar loads), witness slots live in LDS (the
+// on-chip window) or in a per-workgroup region of device memory.
+//
+// The reference has no evaluator to mirror (/root/reference/src/ast.rs:12 makes
+// `Field` a `String`); what a tape op means is the Circom operator its Expr
+// variant prints as (/root/reference/src/circom.rs:35-157).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../../include/zkir_hip.h"
+#include "device_structs.h"
+#include "fr32.cuh"
+
+namespace zkir {
+
+constexpr int kBlock = ZKIR_BLOCK_THREADS;  // lanes (input vectors) per workgroup pass
+
+// Tapes, constants and tape descriptors are read-only for the whole launch and
+// addressed wave-uniformly.  Reading them through the constant address space makes
+// the compiler fetch them with scalar loads into SGPRs, so the opcode dispatch is
+// scalar branches, not per-lane exec masking.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZKIR_UNIFORM __attribute__((address_space(4)))
+#else
+#define ZKIR_UNIFORM  // host pass only parses the kernels
+#endif
+typedef const ZKIR_UNIFORM zkir_op* uniform_ops_t;
+typedef const ZKIR_UNIFORM uint32_t* uniform_u32_t;
+typedef const ZKIR_UNIFORM TapeDesc* uniform_desc_t;
+
+// ---- slot storage -------------------------------------------------------
+// A slot of a 256-lane workgroup is two planes of 256 x 16 bytes: lane t keeps
+// limbs 0..3 at plane 0, limbs 4..7 at plane 1.  Consecutive lanes are 16 bytes
+// apart, so every access is one 128-bit instruction per plane: conflict-free
+// in LDS, fully coalesced in device memory.
+__device__ __forceinline__ Fr load_slot(const uint4* base, uint32_t slot) {
+  const uint4* p = base + (size_t)slot * 2 * kBlock + threadIdx.x;
+  uint4 lo = p[0], hi = p[kBlock];
+  return Fr{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+}
+__device__ __forceinline__ void store_slot(uint4* base, uint32_t slot, const Fr& v) {
+  uint4* p = base + (size_t)slot * 2 * kBlock + threadIdx.x;
+  p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  p[kBlock] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+struct LaneCtx {
+  uint4* gslots;        // this workgroup's device-memory slots
+  uint4* lslots;        // this workgroup's LDS slots
+  uniform_u32_t consts;  // Montgomery-form constant pool of the tape
+};
+
+__device__ __forceinline__ Fr load_operand(uint32_t o, const Fr& acc, const LaneCtx& cx) {
+  const uint32_t kind = o >> ZKIR_KIND_SHIFT, idx = o & ZKIR_INDEX_MASK;
+  if (kind == ZKIR_KIND_ACC) return acc;
+  if (kind == ZKIR_KIND_LSLOT) return load_slot(cx.lslots, idx);
+  if (kind == ZKIR_KIND_CONST) {
+    uniform_u32_t c = cx.consts + (size_t)idx * 8;
+    return Fr{{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]}};
+  }
+  return load_slot(cx.gslots, idx);
+}
+__device__ __forceinline__ void store_operand(uint32_t o, const Fr& v, const LaneCtx& cx) {
+  const uint32_t kind = o >> ZKIR_KIND_SHIFT, idx = o & ZKIR_INDEX_MASK;
+  if (kind == ZKIR_KIND_LSLOT)
+    store_slot(cx.lslots, idx, v);
+  else if (kind == ZKIR_KIND_GSLOT)
+    store_slot(cx.gslots, idx, v);
+}
+
+// ---- the operators that are not + - * -----------------------------------
+// Kept out of line: they are rare in tapes and each holds several copies of the
+// multiplier.  x, y are Montgomery form; the result is Montgomery form.
+struct SlowResult {
+  Fr r;
+  uint32_t fault;  // 1 when the lane divided by zero
+};
+__device__ __forceinline__ Fr slow_op_body(uint32_t code, const Fr& x, const Fr& y, uint32_t* fault) {
+  const Fr one = fr_one_mont();
+  switch (code) {
+    case ZKIR_OP_POW:
+      return fr_pow_mont(x, fr_from_mont(y));
+    case ZKIR_OP_DIV: {
+      if (u256_is_zero(y)) *fault += 1;
+      return fr_mul(x, fr_inv_mont(y));  // inverse of 0 is 0
+    }
+    default:
+      break;
+  }
+  // everything below works on the canonical integers
+  const Fr a = fr_from_mont(x);
+  const Fr b = fr_from_mont(y);
+  bool flag = false, is_flag = true;
+  Fr r = fr_zero();
+  switch (code) {
+    case ZKIR_OP_LT: flag = fr_signed_lt(a, b); break;
+    case ZKIR_OP_LE: flag = !fr_signed_lt(b, a); break;
+    case ZKIR_OP_GT: flag = fr_signed_lt(b, a); break;
+    case ZKIR_OP_GE: flag = !fr_signed_lt(a, b); break;
+    case ZKIR_OP_EQ: flag = u256_eq(a, b); break;
+    case ZKIR_OP_AND: flag = !u256_is_zero(a) && !u256_is_zero(b); break;
+    case ZKIR_OP_OR: flag = !u256_is_zero(a) || !u256_is_zero(b); break;
+    default: is_flag = false; break;
+  }
+  if (is_flag) return fr_select(flag, one, r);
+  switch (code) {
+    case ZKIR_OP_IDIV:
+    case ZKIR_OP_REM: {
+      const bool z = u256_is_zero(b);
+      if (z) *fault += 1;
+      Fr q, m;
+      u256_divrem(a, fr_select(z, fr_small(1), b), q, m);
+      r = (code == ZKIR_OP_IDIV) ? q : m;
+      r = fr_select(z, fr_zero(), r);
+      break;
+    }
+    case ZKIR_OP_BAND:
+#pragma unroll
+      for (int i = 0; i < 8; i++) r.l[i] = a.l[i] & b.l[i];
+      break;  // <= min(a, b) < p
+    case ZKIR_OP_BOR:
+#pragma unroll
+      for (int i = 0; i < 8; i++) r.l[i] = a.l[i] | b.l[i];
+      r = fr_reduce_once(r);  // < 2^254 < 2p
+      break;
+    case ZKIR_OP_BXOR:
+#pragma unroll
+      for (int i = 0; i < 8; i++) r.l[i] = a.l[i] ^ b.l[i];
+      r = fr_reduce_once(r);
+      break;
+    case ZKIR_OP_BNOT:
+#pragma unroll
+      for (int i = 0; i < 8; i++) r.l[i] = ~a.l[i];
+      r = fr_mask254_reduce(r);
+      break;
+    case ZKIR_OP_BNOT256: {
+      // 2^256 - 1 - a is below 6p: subtract 4p, 2p, p as needed
+#pragma unroll
+      for (int i = 0; i < 8; i++) r.l[i] = ~a.l[i];
+      Fr p2, p4, d;
+      u256_add(p2, fr_p(), fr_p());
+      u256_add(p4, p2, p2);
+      uint32_t bw = u256_sub(d, r, p4);
+      r = fr_select(bw != 0, r, d);
+      bw = u256_sub(d, r, p2);
+      r = fr_select(bw != 0, r, d);
+      r = fr_reduce_once(r);
+      break;
+    }
+    case ZKIR_OP_SHR: r = fr_shift(a, b, true); break;
+    case ZKIR_OP_SHL: r = fr_shift(a, b, false); break;
+    default: break;
+  }
+  return fr_to_mont(r);
+}
+__device__ __noinline__ SlowResult slow_op(uint32_t code, Fr x, Fr y) {
+  SlowResult o;
+  o.fault = 0;
+  o.r = slow_op_body(code, x, y, &o.fault);
+  return o;
+}
+
+// ---- the interpreter ------------------------------------------------------
+// Work item w = (tape, pass): workgroup `blockIdx.x` takes w = blockIdx.x,
+// blockIdx.x + gridDim.x, ... so the grid can be sized to the machine and the
+// per-workgroup slot region is reused from pass to pass.
+__global__ void __launch_bounds__(kBlock, 2)
+zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_t passes_per_tape,
+                   uint64_t n_vectors,  // vectors per tape
+                   const uint32_t* __restrict__ inputs, uint32_t* __restrict__ outputs,
+                   uint4* __restrict__ gslot_pool, uint32_t gslots_per_block,
+                   uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats) {
+  extern __shared__ uint4 lds_slots[];
+  LaneCtx cx;
+  cx.lslots = lds_slots;
+  cx.gslots = gslot_pool + (size_t)blockIdx.x * gslots_per_block * 2 * kBlock;
+
+  const uint64_t total = (uint64_t)n_tapes * passes_per_tape;
+  for (uint64_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const uint32_t tape_i = (uint32_t)(w / passes_per_tape);
+    const uint32_t pass = (uint32_t)(w % passes_per_tape);
+    const TapeDesc td = ((uniform_desc_t)tapes)[tape_i];
+    cx.consts = (uniform_u32_t)td.consts;
+    uniform_ops_t ops = (uniform_ops_t)td.ops;
+    const uint64_t vec = (uint64_t)pass * kBlock + threadIdx.x;
+    const bool live = vec < n_vectors;
+    const uint64_t v = live ? vec : 0;  // idle lanes recompute vector 0 and report nothing
+    const uint32_t* in = inputs + td.in_word_off + v;
+    uint32_t* out = outputs ? outputs + td.out_word_off + v : nullptr;
+
+    Fr acc = fr_zero();
+    uint32_t fault = 0, first_bad = 0xffffffffu, check_k = 0;
+    uint64_t wave_unsat = 0;
+
+    for (uint32_t pc = 0; pc < td.n_ops; pc++) {
+      const zkir_op op = ops[pc];
+      const uint32_t code = op.code & 0xffu;
+      Fr x, y = fr_zero();
+      if (code == ZKIR_OP_INPUT) {
+        const uint32_t* q = in + (size_t)(op.a & ZKIR_INDEX_MASK) * 8 * n_vectors;
+#pragma unroll
+        for (int i = 0; i < 8; i++) x.l[i] = q[(size_t)i * n_vectors];
+        y = fr_r2();
+      } else if (code == ZKIR_OP_NOP) {
+        continue;
+      } else {
+        x = load_operand(op.a, acc, cx);
+        if (code >= ZKIR_OP_ADD) y = load_operand(op.b, acc, cx);
+        if (code == ZKIR_OP_OUTPUT) y = fr_small(1);
+      }
+
+      Fr r;
+      if (code == ZKIR_OP_MUL || code == ZKIR_OP_CHECK || code == ZKIR_OP_INPUT || code == ZKIR_OP_OUTPUT) {
+        r = fr_mul(x, y);
+      } else if (code == ZKIR_OP_ADD) {
+        r = fr_add(x, y);
+      } else if (code == ZKIR_OP_SUB) {
+        r = fr_sub(x, y);
+      } else if (code == ZKIR_OP_COPY) {
+        r = x;
+      } else if (code == ZKIR_OP_NEG) {
+        r = fr_neg(x);
+      } else {
+        const SlowResult sr = slow_op(code, x, y);
+        r = sr.r;
+        fault |= sr.fault;
+      }
+
+      if (code == ZKIR_OP_CHECK) {
+        const Fr c = load_operand(op.dst, acc, cx);
+        const bool bad = live && !u256_eq(r, c);
+        wave_unsat += __popcll(__ballot(bad));
+        if (bad && first_bad == 0xffffffffu) first_bad = check_k;
+        check_k++;
+      } else if (code == ZKIR_OP_OUTPUT) {
+        if (out && live) {
+          uint32_t* q = out + (size_t)op.dst * 8 * n_vectors;
+#pragma unroll
+          for (int i = 0; i < 8; i++) q[(size_t)i * n_vectors] = r.l[i];
+        }
+      } else {
+        acc = r;
+        store_operand(op.dst, r, cx);
+      }
+    }
+
+    // one atomic per wave for the counters, one per failing lane for the minimum
+    const uint64_t wave_faults = __popcll(__ballot(live && fault != 0));
+    if ((threadIdx.x & 63) == 0) {
+      if (wave_unsat) atomicAdd((unsigned long long*)&unsat_per_tape[tape_i], (unsigned long long)wave_unsat);
+      if (wave_faults) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)wave_faults);
+    }
+    if (first_bad != 0xffffffffu)
+      atomicMin((unsigned long long*)&stats[0], (unsigned long long)((vec << 32) | first_bad));
+  }
+}
+
+// constants arrive canonical; rewrite them in Montgomery form in place
+__global__ void zkir_consts_to_mont_kernel(uint32_t* consts, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr a;
+#pragma unroll
+  for (int k = 0; k < 8; k++) a.l[k] = consts[(size_t)i * 8 + k];
+  a = fr_to_mont(a);
+#pragma unroll
+  for (int k = 0; k < 8; k++) consts[(size_t)i * 8 + k] = a.l[k];
+}
+
+// ---- peak-rate probes ------------------------------------------------------
+// Issue rate of one integer multiply instruction: 8 independent dependency
+// chains per lane, 16 instructions per loop trip, nothing else in the loop.
+template <int WHICH>
+__global__ void __launch_bounds__(256) zkir_int_mul_rate_kernel(uint32_t* out, uint32_t seed, int iters) {
+  uint32_t a[8], b = seed | 1u, c = seed * 3u + 7u;
+  uint64_t q[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    a[i] = threadIdx.x * 8 + i + seed;
+    q[i] = a[i];
+  }
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+#pragma unroll
+      for (int n = 0; n < 8; n++) {
+        if (WHICH == 0) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[n]) : "v"(b));
+        if (WHICH == 1) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[n]) : "v"(b));
+        if (WHICH == 2) {
+          uint64_t sink;
+          asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(q[n]), "=s"(sink) : "v"(b), "v"(c));
+        }
+      }
+    }
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s ^= a[i] ^ (uint32_t)q[i] ^ (uint32_t)(q[i] >> 32);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// Montgomery multiplications back to back in registers: two independent chains per lane.
+__global__ void __launch_bounds__(256) zkir_fr_mul_rate_kernel(uint32_t* out, uint32_t seed, int iters) {
+  Fr x = fr_one_mont(), y = fr_r2();
+  x.l[0] ^= threadIdx.x + seed;
+  x.l[7] &= 0x0fffffffu;
+  y.l[0] ^= blockIdx.x;
+  y.l[7] &= 0x0fffffffu;
+  for (int it = 0; it < iters; it++) {
+    x = fr_mul(x, y);
+    y = fr_mul(y, x);
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s ^= x.l[i] ^ y.l[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+}  // namespace zkir
+
+// ---- host-callable launchers (C++ linkage, used by runtime.cpp) ------------
+namespace zkir {
+
+hipError_t launch_interp(const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape, uint64_t n_vectors,
+                         const uint32_t* inputs, uint32_t* outputs, void* gslot_pool, uint32_t gslots_per_block,
+                         uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats, uint32_t grid, hipStream_t stream) {
+  const size_t lds_bytes = (size_t)lslots * 2 * kBlock * sizeof(uint4);
+  if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS limit the kernel must opt in
+    hipError_t e = hipFuncSetAttribute((const void*)zkir_interp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(zkir_interp_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, tapes_dev, n_tapes,
+                     passes_per_tape, n_vectors, inputs, outputs, (uint4*)gslot_pool, gslots_per_block, unsat_per_tape,
+                     stats);
+  return hipGetLastError();
+}
+
+hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(zkir_consts_to_mont_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, consts_dev, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_int_mul_rate(int which, uint32_t* out, uint32_t blocks, int iters, hipStream_t stream) {
+  switch (which) {
+    case 0: hipLaunchKernelGGL(zkir_int_mul_rate_kernel<0>, dim3(blocks), dim3(256), 0, stream, out, 12345u, iters); break;
+    case 1: hipLaunchKernelGGL(zkir_int_mul_rate_kernel<1>, dim3(blocks), dim3(256), 0, stream, out, 12345u, iters); break;
+    default: hipLaunchKernelGGL(zkir_int_mul_rate_kernel<2>, dim3(blocks), dim3(256), 0, stream, out, 12345u, iters); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_fr_mul_rate(uint32_t* out, uint32_t blocks, int iters, hipStream_t stream) {
+  hipLaunchKernelGGL(zkir_fr_mul_rate_kernel, dim3(blocks), dim3(256), 0, stream, out, 777u, iters);
+  return hipGetLastError();
+}
+
+}  // namespace zkir

@@ -1,0 +1,370 @@
+// Host runtime behind the device half of include/zkir_hip.h: contexts, tape
+// upload, launches.  Nothing here computes field arithmetic on the CPU; if no
+// gfx950 device is present every call fails with ZKIR_E_NODEVICE / ZKIR_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../../include/zkir_hip.h"
+#include "device_structs.h"
+#include "tape_check.h"
+
+namespace zkir {
+hipError_t launch_interp(const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape, uint64_t n_vectors,
+                         const uint32_t* inputs, uint32_t* outputs, void* gslot_pool, uint32_t gslots_per_block,
+                         uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats, uint32_t grid, hipStream_t stream);
+hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream);
+hipError_t launch_int_mul_rate(int which, uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
+hipError_t launch_fr_mul_rate(uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
+}  // namespace zkir
+
+using zkir::TapeDesc;
+
+struct DevTape {
+  zkir_tape_hdr hdr{};
+  void* ops = nullptr;     // device
+  void* consts = nullptr;  // device, Montgomery form
+};
+
+struct zkir_ctx {
+  int device = 0;
+  int n_cu = 0;
+  std::string err;
+  std::map<zkir_tape_id, DevTape> tapes;
+  zkir_tape_id next_id = 1;
+  // growable device buffers owned by the context
+  void* gslot_pool = nullptr;
+  size_t gslot_pool_bytes = 0;
+  void* desc_buf = nullptr;
+  size_t desc_buf_bytes = 0;
+  void* result_buf = nullptr;  // 4 x uint64 for the host-pointer entry points
+  void* io_in = nullptr;
+  size_t io_in_bytes = 0;
+  void* io_out = nullptr;
+  size_t io_out_bytes = 0;
+  void* io_unsat = nullptr;
+  size_t io_unsat_bytes = 0;
+  uint64_t last_faults = 0;
+};
+
+namespace {
+
+int32_t fail(zkir_ctx* ctx, int32_t code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+int32_t hip_fail(zkir_ctx* ctx, hipError_t e, const char* what) {
+  return fail(ctx, ZKIR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(ctx, expr)                                  \
+  do {                                                      \
+    hipError_t e_ = (expr);                                 \
+    if (e_ != hipSuccess) return hip_fail(ctx, e_, #expr);  \
+  } while (0)
+
+int32_t ensure(zkir_ctx* ctx, void** buf, size_t* have, size_t need) {
+  if (*have >= need && *buf) return ZKIR_OK;
+  if (*buf) {
+    HIP_TRY(ctx, hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+  }
+  size_t sz = std::max<size_t>(need, 256);
+  hipError_t e = hipMalloc(buf, sz);
+  if (e != hipSuccess) return fail(ctx, ZKIR_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  *have = sz;
+  return ZKIR_OK;
+}
+
+// Grid: enough workgroups to fill the machine, never more than there is work.
+// The kernel is bounded to 2 waves/SIMD at 256 threads, i.e. up to 2-3 workgroups
+// per CU depending on the LDS window; extra workgroups only queue.
+uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, uint32_t lslots) {
+  uint32_t per_cu = 3;
+  if (lslots > 0) {
+    size_t lds = (size_t)lslots * 2 * ZKIR_BLOCK_THREADS * 16;
+    per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / lds));
+  }
+  uint64_t g = (uint64_t)ctx->n_cu * per_cu;
+  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, work_items));
+}
+
+struct Launch {
+  std::vector<TapeDesc> descs;
+  uint32_t max_gslots = 0, max_lslots = 0;
+};
+
+int32_t build_launch(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, uint64_t N, Launch* L) {
+  uint64_t in_off = 0, out_off = 0;
+  L->descs.resize(n);
+  for (uint32_t i = 0; i < n; i++) {
+    auto it = ctx->tapes.find(ids[i]);
+    if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
+    const DevTape& t = it->second;
+    TapeDesc& d = L->descs[i];
+    std::memset(&d, 0, sizeof d);
+    d.ops = (const zkir_op*)t.ops;
+    d.consts = (const uint32_t*)t.consts;
+    d.in_word_off = in_off;
+    d.out_word_off = out_off;
+    d.n_ops = t.hdr.n_ops;
+    d.n_inputs = t.hdr.n_inputs;
+    d.n_outputs = t.hdr.n_outputs;
+    d.n_constraints = t.hdr.n_constraints;
+    in_off += (uint64_t)t.hdr.n_inputs * 8 * N;
+    out_off += (uint64_t)t.hdr.n_outputs * 8 * N;
+    L->max_gslots = std::max(L->max_gslots, t.hdr.n_gslots);
+    L->max_lslots = std::max(L->max_lslots, t.hdr.n_lslots);
+  }
+  return ZKIR_OK;
+}
+
+// Launch the interpreter on device buffers.  unsat_dev has n entries, stats_dev 2
+// entries ({packed first unsat, faults}); both must already be initialised.
+int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint32_t* in_dev, uint64_t N,
+                  uint32_t* out_dev, uint64_t* unsat_dev, uint64_t* stats_dev, hipStream_t stream) {
+  if (N == 0 || n == 0) return ZKIR_OK;
+  if (N >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "N must be below 2^32");
+  Launch L;
+  int32_t rc = build_launch(ctx, ids, n, N, &L);
+  if (rc) return rc;
+  const uint32_t passes = (uint32_t)((N + ZKIR_BLOCK_THREADS - 1) / ZKIR_BLOCK_THREADS);
+  const uint64_t work = (uint64_t)n * passes;
+  const uint32_t grid = pick_grid(ctx, work, L.max_lslots);
+  const size_t slot_bytes = (size_t)2 * ZKIR_BLOCK_THREADS * 16;
+  rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, (size_t)grid * L.max_gslots * slot_bytes);
+  if (rc) return rc;
+  rc = ensure(ctx, &ctx->desc_buf, &ctx->desc_buf_bytes, (size_t)n * sizeof(TapeDesc));
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->desc_buf, L.descs.data(), (size_t)n * sizeof(TapeDesc), hipMemcpyHostToDevice, stream));
+  // L.descs is pageable host memory: hipMemcpyAsync has consumed it when it returns,
+  // and the device-side staging buffer is only rewritten by later work on `stream`.
+  hipError_t e = zkir::launch_interp((const TapeDesc*)ctx->desc_buf, n, passes, N, in_dev, out_dev, ctx->gslot_pool,
+                                     L.max_gslots, L.max_lslots, unsat_dev, stats_dev, grid, stream);
+  if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
+  return ZKIR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t zkir_ctx_create(int32_t device, zkir_ctx** out) {
+  if (!out) return ZKIR_E_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZKIR_E_NODEVICE;
+  if (device < 0 || device >= count) return ZKIR_E_INVALID;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ZKIR_E_HIP;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ZKIR_E_NODEVICE;  // kernels are gfx950 only
+  zkir_ctx* ctx = new (std::nothrow) zkir_ctx();
+  if (!ctx) return ZKIR_E_NOMEM;
+  ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount;
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->result_buf, 4 * sizeof(uint64_t)) != hipSuccess) {
+    delete ctx;
+    return ZKIR_E_HIP;
+  }
+  *out = ctx;
+  return ZKIR_OK;
+}
+
+int32_t zkir_ctx_destroy(zkir_ctx* ctx) {
+  if (!ctx) return ZKIR_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : ctx->tapes) {
+    (void)hipFree(kv.second.ops);
+    (void)hipFree(kv.second.consts);
+  }
+  void* bufs[] = {ctx->gslot_pool, ctx->desc_buf, ctx->result_buf, ctx->io_in, ctx->io_out, ctx->io_unsat};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  delete ctx;
+  return ZKIR_OK;
+}
+
+const char* zkir_last_error(const zkir_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int32_t zkir_tape_upload(zkir_ctx* ctx, const zkir_tape_hdr* hdr, const void* blob, size_t bytes, zkir_tape_id* out) {
+  if (!ctx || !hdr || !out) return ZKIR_E_INVALID;
+  std::string why;
+  if (!zkir::check_tape(*hdr, blob, bytes, &why)) return fail(ctx, ZKIR_E_INVALID, "bad tape: " + why);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevTape t;
+  t.hdr = *hdr;
+  const size_t ops_bytes = (size_t)hdr->n_ops * sizeof(zkir_op);
+  const size_t consts_bytes = (size_t)hdr->n_consts * 32;
+  if (hipMalloc(&t.ops, std::max<size_t>(ops_bytes, 16)) != hipSuccess) return fail(ctx, ZKIR_E_NOMEM, "hipMalloc ops");
+  if (hipMalloc(&t.consts, std::max<size_t>(consts_bytes, 32)) != hipSuccess) {
+    (void)hipFree(t.ops);
+    return fail(ctx, ZKIR_E_NOMEM, "hipMalloc consts");
+  }
+  hipError_t e = hipSuccess;
+  if (ops_bytes) e = hipMemcpy(t.ops, blob, ops_bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess && consts_bytes)
+    e = hipMemcpy(t.consts, (const char*)blob + ops_bytes, consts_bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = zkir::launch_consts_to_mont((uint32_t*)t.consts, hdr->n_consts, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipFree(t.ops);
+    (void)hipFree(t.consts);
+    return hip_fail(ctx, e, "tape upload");
+  }
+  *out = ctx->next_id++;
+  ctx->tapes[*out] = t;
+  return ZKIR_OK;
+}
+
+int32_t zkir_tape_release(zkir_ctx* ctx, zkir_tape_id id) {
+  if (!ctx) return ZKIR_E_INVALID;
+  auto it = ctx->tapes.find(id);
+  if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  (void)hipFree(it->second.ops);
+  (void)hipFree(it->second.consts);
+  ctx->tapes.erase(it);
+  return ZKIR_OK;
+}
+
+int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa_dev, uint64_t N,
+                            uint32_t* outputs_soa_dev, uint64_t* result_dev, void* stream) {
+  if (!ctx || !result_dev) return ZKIR_E_INVALID;
+  auto it = ctx->tapes.find(tape);
+  if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
+  if (it->second.hdr.n_inputs && N && !inputs_soa_dev) return fail(ctx, ZKIR_E_INVALID, "inputs required");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t init[4] = {0, ~0ull, 0, 0};
+  HIP_TRY(ctx, hipMemcpyAsync(result_dev, init, sizeof init, hipMemcpyHostToDevice, s));
+  return run_tapes(ctx, &tape, 1, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s);
+}
+
+int32_t zkir_eval_batch(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa, uint64_t N, uint32_t* outputs_soa,
+                        uint64_t* unsat_count, uint32_t* first_unsat) {
+  if (!ctx || !unsat_count) return ZKIR_E_INVALID;
+  auto it = ctx->tapes.find(tape);
+  if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
+  const zkir_tape_hdr& h = it->second.hdr;
+  if (h.n_inputs && N && !inputs_soa) return fail(ctx, ZKIR_E_INVALID, "inputs required");
+  if (N >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "N must be below 2^32");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t in_bytes = (size_t)h.n_inputs * 32 * N, out_bytes = (size_t)h.n_outputs * 32 * N;
+  int32_t rc = ensure(ctx, &ctx->io_in, &ctx->io_in_bytes, in_bytes);
+  if (rc) return rc;
+  if (outputs_soa) {
+    rc = ensure(ctx, &ctx->io_out, &ctx->io_out_bytes, out_bytes);
+    if (rc) return rc;
+  }
+  if (in_bytes) HIP_TRY(ctx, hipMemcpy(ctx->io_in, inputs_soa, in_bytes, hipMemcpyHostToDevice));
+  rc = zkir_eval_batch_dev(ctx, tape, (const uint32_t*)ctx->io_in, N, outputs_soa ? (uint32_t*)ctx->io_out : nullptr,
+                           (uint64_t*)ctx->result_buf, nullptr);
+  if (rc) return rc;
+  uint64_t res[4];
+  HIP_TRY(ctx, hipMemcpy(res, ctx->result_buf, sizeof res, hipMemcpyDeviceToHost));
+  if (outputs_soa && out_bytes) HIP_TRY(ctx, hipMemcpy(outputs_soa, ctx->io_out, out_bytes, hipMemcpyDeviceToHost));
+  *unsat_count = res[0];
+  ctx->last_faults = res[2];
+  if (first_unsat) {
+    first_unsat[0] = res[1] == ~0ull ? 0xffffffffu : (uint32_t)(res[1] >> 32);
+    first_unsat[1] = res[1] == ~0ull ? 0xffffffffu : (uint32_t)(res[1] & 0xffffffffu);
+  }
+  return ZKIR_OK;
+}
+
+int32_t zkir_eval_multi_dev(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs_dev,
+                            uint64_t N_per_tape, uint64_t* per_tape_unsat_dev, void* stream) {
+  if (!ctx || (!tapes && n_tapes) || (!per_tape_unsat_dev && n_tapes)) return ZKIR_E_INVALID;
+  if (n_tapes == 0) return ZKIR_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(ctx, hipMemsetAsync(per_tape_unsat_dev, 0, (size_t)n_tapes * sizeof(uint64_t), s));
+  const uint64_t init[4] = {0, ~0ull, 0, 0};
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->result_buf, init, sizeof init, hipMemcpyHostToDevice, s));
+  return run_tapes(ctx, tapes, n_tapes, inputs_dev, N_per_tape, nullptr, per_tape_unsat_dev,
+                   (uint64_t*)ctx->result_buf + 1, s);
+}
+
+int32_t zkir_eval_multi(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs,
+                        uint64_t N_per_tape, uint64_t* per_tape_unsat) {
+  if (!ctx || (!tapes && n_tapes) || (!per_tape_unsat && n_tapes)) return ZKIR_E_INVALID;
+  if (n_tapes == 0) return ZKIR_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t in_bytes = 0;
+  for (uint32_t i = 0; i < n_tapes; i++) {
+    auto it = ctx->tapes.find(tapes[i]);
+    if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
+    in_bytes += (size_t)it->second.hdr.n_inputs * 32 * N_per_tape;
+  }
+  if (in_bytes && !inputs) return fail(ctx, ZKIR_E_INVALID, "inputs required");
+  int32_t rc = ensure(ctx, &ctx->io_in, &ctx->io_in_bytes, in_bytes);
+  if (rc) return rc;
+  rc = ensure(ctx, &ctx->io_unsat, &ctx->io_unsat_bytes, (size_t)n_tapes * sizeof(uint64_t));
+  if (rc) return rc;
+  if (in_bytes) HIP_TRY(ctx, hipMemcpy(ctx->io_in, inputs, in_bytes, hipMemcpyHostToDevice));
+  rc = zkir_eval_multi_dev(ctx, tapes, n_tapes, (const uint32_t*)ctx->io_in, N_per_tape, (uint64_t*)ctx->io_unsat,
+                           nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(per_tape_unsat, ctx->io_unsat, (size_t)n_tapes * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  uint64_t res[4];
+  HIP_TRY(ctx, hipMemcpy(res, ctx->result_buf, sizeof res, hipMemcpyDeviceToHost));
+  ctx->last_faults = res[2];
+  return ZKIR_OK;
+}
+
+int32_t zkir_last_faults(const zkir_ctx* ctx, uint64_t* faults) {
+  if (!ctx || !faults) return ZKIR_E_INVALID;
+  *faults = ctx->last_faults;
+  return ZKIR_OK;
+}
+
+static int32_t time_probe(zkir_ctx* ctx, int which, bool fr, double* out) {
+  if (!ctx || !out) return ZKIR_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint32_t blocks = (uint32_t)ctx->n_cu * 8;  // 8 waves per SIMD
+  const int iters = fr ? 64 : 2048;
+  uint32_t* buf = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&buf, (size_t)blocks * 256 * 4));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  auto launch = [&]() {
+    return fr ? zkir::launch_fr_mul_rate(buf, blocks, iters, nullptr)
+              : zkir::launch_int_mul_rate(which, buf, blocks, iters, nullptr);
+  };
+  hipError_t e = launch();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  const int reps = 5;
+  if (e == hipSuccess) {
+    (void)hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps && e == hipSuccess; r++) e = launch();
+    (void)hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+  }
+  float ms = 0;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return hip_fail(ctx, e, "rate probe");
+  const double per_lane = fr ? 2.0 * iters : 16.0 * iters;
+  *out = (double)blocks * 256 * per_lane * reps / (ms * 1e-3);
+  return ZKIR_OK;
+}
+
+int32_t zkir_measure_int_mul_rate(zkir_ctx* ctx, int32_t which, double* lane_ops_per_s) {
+  if (which < 0 || which > 2) return ZKIR_E_INVALID;
+  return time_probe(ctx, which, false, lane_ops_per_s);
+}
+
+int32_t zkir_measure_fr_mul_rate(zkir_ctx* ctx, double* fr_mul_per_s) { return time_probe(ctx, 0, true, fr_mul_per_s); }
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+// The host half of include/zkir_hip.h: the reference-side mirror (generate, print,
+// transpile) and lower, behind a C boundary that never lets an exception through.
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../../include/zkir_hip.h"
+#include "../hip/tape_check.h"
+#include "ast.hpp"
+#include "circom.hpp"
+#include "gadget.hpp"
+#include "generator.hpp"
+#include "lower.hpp"
+#include "rng.hpp"
+#include "sexpr.hpp"
+
+namespace {
+
+thread_local std::string g_host_error;
+
+int32_t copy_out(const std::string& s, char* buf, size_t cap, size_t* needed) {
+  if (needed) *needed = s.size() + 1;
+  if (!buf || cap < s.size() + 1) return ZKIR_E_BUFSIZE;
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return ZKIR_OK;
+}
+
+template <class F>
+int32_t guarded(F f) {
+  try {
+    return f();
+  } catch (const zkir::LowerError& e) {
+    g_host_error = e.what();
+    return ZKIR_E_LOWER;
+  } catch (const std::bad_alloc&) {
+    g_host_error = "out of memory";
+    return ZKIR_E_NOMEM;
+  } catch (const std::invalid_argument& e) {
+    g_host_error = e.what();
+    return ZKIR_E_INVALID;
+  } catch (const std::exception& e) {
+    g_host_error = e.what();
+    return ZKIR_E_INTERNAL;
+  } catch (...) {
+    g_host_error = "unknown exception";
+    return ZKIR_E_INTERNAL;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// message of the last failing host-side call on this thread
+const char* zkir_host_last_error(void) { return g_host_error.c_str(); }
+
+int32_t zkir_generator_config_default(zkir_generator_config* cfg) {
+  if (!cfg) return ZKIR_E_INVALID;
+  *cfg = zkir::default_generator_config();
+  return ZKIR_OK;
+}
+
+int32_t zkir_generate(uint64_t seed, const zkir_generator_config* cfg, zkir_circuit** out) {
+  if (!out) return ZKIR_E_INVALID;
+  *out = nullptr;
+  return guarded([&]() -> int32_t {
+    zkir::GeneratorConfig c = cfg ? *cfg : zkir::default_generator_config();
+    if (c.min_instructions > c.max_instructions || c.max_array_len == 0 || c.loop_body_max == 0 ||
+        c.max_instructions > (1u << 22) || c.name_len == 0 || c.name_len > 64 || c.max_expr_depth > 64 ||
+        c.loop_init_max > c.loop_bound_max)
+      throw std::invalid_argument("generator config out of range");
+    zkir::Generator g(zkir::Rng::from_seed(seed), c);
+    auto* h = new zkir_circuit();
+    h->circuit = g.generate();
+    *out = h;
+    return ZKIR_OK;
+  });
+}
+
+int32_t zkir_rng_stream(uint64_t seed, uint32_t n, uint64_t* out_vals) {
+  if (!out_vals && n) return ZKIR_E_INVALID;
+  return guarded([&]() -> int32_t {
+    zkir::Rng r = zkir::Rng::from_seed(seed);
+    for (uint32_t i = 0; i < n; i++) out_vals[i] = r.next();
+    return ZKIR_OK;
+  });
+}
+
+int32_t zkir_circuit_parse(const char* text, zkir_circuit** out) {
+  if (!text || !out) return ZKIR_E_INVALID;
+  *out = nullptr;
+  return guarded([&]() -> int32_t {
+    zkir::Circuit c;
+    try {
+      c = zkir::parse_circuit(text);
+    } catch (const std::runtime_error& e) {
+      throw std::invalid_argument(e.what());
+    }
+    auto* h = new zkir_circuit();
+    h->circuit = std::move(c);
+    *out = h;
+    return ZKIR_OK;
+  });
+}
+
+int32_t zkir_circuit_print(const zkir_circuit* c, char* buf, size_t cap, size_t* needed) {
+  if (!c) return ZKIR_E_INVALID;
+  return guarded([&]() -> int32_t { return copy_out(zkir::print_circuit(c->circuit), buf, cap, needed); });
+}
+
+int32_t zkir_circuit_transpile_circom(const zkir_circuit* c, char* buf, size_t cap, size_t* needed) {
+  if (!c) return ZKIR_E_INVALID;
+  return guarded([&]() -> int32_t {
+    zkir::CircomTranspiler t(c->circuit);
+    return copy_out(t.transpile_circuit(), buf, cap, needed);
+  });
+}
+
+int32_t zkir_circuit_debug(const zkir_circuit* c, char* buf, size_t cap, size_t* needed) {
+  if (!c) return ZKIR_E_INVALID;
+  return guarded([&]() -> int32_t { return copy_out(zkir::debug_instructions(c->circuit.instructions), buf, cap, needed); });
+}
+
+void zkir_circuit_free(zkir_circuit* c) { delete c; }
+
+int32_t zkir_gadget_poseidon_style(uint32_t width, uint32_t rounds, uint64_t seed, zkir_circuit** out) {
+  if (!out) return ZKIR_E_INVALID;
+  *out = nullptr;
+  return guarded([&]() -> int32_t {
+    if ((uint64_t)width * rounds > (1u << 22)) throw std::invalid_argument("gadget too large");
+    auto* h = new zkir_circuit();
+    h->circuit = zkir::poseidon_style_gadget(width, rounds, seed);
+    *out = h;
+    return ZKIR_OK;
+  });
+}
+
+int32_t zkir_lower_options_default(zkir_lower_options* o) {
+  if (!o) return ZKIR_E_INVALID;
+  *o = zkir::default_lower_options();
+  return ZKIR_OK;
+}
+
+int32_t zkir_lower(const zkir_circuit* c, const zkir_lower_options* opts, zkir_tape** out, int32_t* status_class) {
+  if (!c || !out) return ZKIR_E_INVALID;
+  *out = nullptr;
+  if (status_class) *status_class = ZKIR_LOWER_OK;
+  try {
+    zkir::LowerOptions o = opts ? *opts : zkir::default_lower_options();
+    zkir::Lowerer lw(c->circuit, o);
+    auto* h = new zkir_tape();
+    try {
+      h->tape = lw.lower();
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+    return ZKIR_OK;
+  } catch (const zkir::LowerError& e) {
+    g_host_error = e.what();
+    if (status_class) *status_class = e.status_class;
+    return ZKIR_E_LOWER;
+  } catch (const std::bad_alloc&) {
+    g_host_error = "out of memory";
+    return ZKIR_E_NOMEM;
+  } catch (const std::exception& e) {
+    g_host_error = e.what();
+    return ZKIR_E_INTERNAL;
+  } catch (...) {
+    g_host_error = "unknown exception";
+    return ZKIR_E_INTERNAL;
+  }
+}
+
+int32_t zkir_tape_header(const zkir_tape* t, zkir_tape_hdr* hdr) {
+  if (!t || !hdr) return ZKIR_E_INVALID;
+  *hdr = t->tape.hdr;
+  return ZKIR_OK;
+}
+
+int32_t zkir_tape_blob(const zkir_tape* t, const void** blob, size_t* bytes) {
+  if (!t || !blob || !bytes) return ZKIR_E_INVALID;
+  *blob = t->tape.blob.data();
+  *bytes = t->tape.blob.size();
+  return ZKIR_OK;
+}
+
+// (var id, offset, len) triples of the input (which = 0) or output (which = 1) signals
+int32_t zkir_tape_io_map(const zkir_tape* t, int32_t which, uint64_t* triples, size_t cap_entries, size_t* n_entries) {
+  if (!t || !n_entries) return ZKIR_E_INVALID;
+  const auto& v = which ? t->tape.outputs : t->tape.inputs;
+  *n_entries = v.size();
+  if (!triples || cap_entries < v.size()) return ZKIR_E_BUFSIZE;
+  for (size_t i = 0; i < v.size(); i++) {
+    triples[3 * i] = v[i].var_id;
+    triples[3 * i + 1] = v[i].offset;
+    triples[3 * i + 2] = v[i].len;
+  }
+  return ZKIR_OK;
+}
+
+int32_t zkir_tape_from_blob(const zkir_tape_hdr* hdr, const void* blob, size_t bytes, zkir_tape** out) {
+  if (!hdr || !out) return ZKIR_E_INVALID;
+  *out = nullptr;
+  return guarded([&]() -> int32_t {
+    std::string why;
+    if (!zkir::check_tape(*hdr, blob, bytes, &why)) throw std::invalid_argument("bad tape: " + why);
+    auto* h = new zkir_tape();
+    h->tape.hdr = *hdr;
+    h->tape.blob.assign((const uint8_t*)blob, (const uint8_t*)blob + bytes);
+    *out = h;
+    return ZKIR_OK;
+  });
+}
+
+void zkir_tape_free(zkir_tape* t) { delete t; }
+
+}  // extern "C"

@@ -1,0 +1,374 @@
+// See generator.hpp.  Function by function this follows the reference's
+// src/generator.rs; the order of every rng_ call is the reference's order, because
+// a seed must reproduce the same circuit here and there.
+#include "generator.hpp"
+
+#include <string>
+
+namespace zkir {
+
+GeneratorConfig default_generator_config() {
+  GeneratorConfig c{};
+  c.min_instructions = 15;  // generator.rs:147
+  c.max_instructions = 30;
+  c.statement_budget = 10;  // generator.rs:167
+  c.max_array_len = 10;     // generator.rs:224
+  c.max_expr_depth = 1;     // generator.rs:486
+  c.loop_init_max = 30;     // generator.rs:406
+  c.loop_bound_max = 60;    // generator.rs:416
+  c.loop_body_max = 5;      // generator.rs:436
+  c.name_len = 8;           // generator.rs:264
+  return c;
+}
+
+// ---- ScopeStack (generator.rs:48-115) ----
+Variable Generator::ScopeStack::add_var(std::string name, VariableType t, VariableRole r,
+                                        std::vector<bool> initialized) {
+  Variable var;
+  var.var_ref.id = next_id;
+  var.name = std::move(name);
+  var.var_type = t;
+  var.role = r;
+  var.initialized = std::move(initialized);
+  stack.back().vars.push_back(var);
+  all_vars.push_back(var);  // a copy taken now: later mark_initialized calls do not reach it (generator.rs:84)
+  next_id += 1;
+  return var;
+}
+
+std::vector<const Variable*> Generator::ScopeStack::get_scope_vars() const {
+  std::vector<const Variable*> r;
+  for (const Scope& s : stack)
+    for (const Variable& v : s.vars) r.push_back(&v);
+  return r;
+}
+
+void Generator::ScopeStack::mark_initialized(const VarRef& var_id) {
+  for (Scope& scope : stack)
+    for (Variable& var : scope.vars)
+      if (var.var_ref.id == var_id.id) {
+        if (var_id.idx)
+          var.initialized.at(*var_id.idx) = true;
+        else
+          var.initialized = std::vector<bool>{true};
+        return;
+      }
+}
+
+// ---- Generator ----
+void Generator::push_generated(std::vector<Instruction>& out, std::optional<Instruction> instr) {
+  if (instr) {
+    for (Instruction& p : pending_) out.push_back(std::move(p));
+    out.push_back(std::move(*instr));
+  }
+  pending_.clear();
+}
+
+Circuit Generator::generate() {
+  std::vector<Instruction> instructions;
+  scope_stack_.enter_scope();
+
+  const size_t n = rng_.rand(cfg_.min_instructions, cfg_.max_instructions);
+  requested_ = n;
+
+  // extension: scalar input signals declared before anything else
+  for (uint32_t k = 0; k < cfg_.forced_inputs; k++) {
+    auto d = gen_var_decl(VariableType::Field(), VariableRole::Signal(SignalType::Input), std::nullopt);
+    instructions.push_back(std::move(*d));
+  }
+
+  for (size_t i = 0; i < n; i++) {
+    std::optional<Instruction> instr = generate_instr();
+    const bool some = instr.has_value();
+    push_generated(instructions, std::move(instr));
+    if (some) n_instr_ = 0;
+  }
+  generated_ = instructions.size();
+
+  scope_stack_.leave_scope();
+  if (!scope_stack_.stack.empty()) throw std::logic_error("scope stack not empty");  // generator.rs:161
+  return Circuit(scope_stack_.all_vars, std::move(instructions));
+}
+
+std::optional<Instruction> Generator::generate_instr() {
+  if (n_instr_ >= cfg_.statement_budget) return std::nullopt;
+  n_instr_ += 1;
+
+  const bool has_vars = has_vars_of_type([](const Variable& v) { return v.role.is_local(); });
+  const bool has_arrays = has_vars_of_type([](const Variable& v) { return v.role.is_local() && v.var_type.is_array; });
+  const bool has_output_signals = has_vars_of_type([](const Variable& v) { return v.role.is_output(); });
+
+  // candidate order of generator.rs:188-204
+  enum Cand { kVarDecl, kFor, kAssign, kArrayAssign, kConstraint };
+  std::vector<Cand> funcs;
+  funcs.push_back(kVarDecl);
+  if (!cfg_.no_loops) funcs.push_back(kFor);
+  if (has_vars) funcs.push_back(kAssign);
+  if (has_arrays) funcs.push_back(kArrayAssign);
+  if (has_output_signals || cfg_.quadratic_aware) funcs.push_back(kConstraint);
+
+  const size_t idx = rng_.rand(0, funcs.size() - 1);
+  switch (funcs[idx]) {
+    case kVarDecl: return gen_var_decl_default();
+    case kFor: return gen_for();
+    case kAssign: return gen_assign();
+    case kArrayAssign: return gen_array_assign();
+    case kConstraint: return cfg_.quadratic_aware ? gen_constraint_quadratic() : gen_constraint();
+  }
+  return std::nullopt;
+}
+
+std::optional<Instruction> Generator::gen_var_decl(std::optional<VariableType> type_kind,
+                                                   std::optional<VariableRole> role_kind,
+                                                   std::optional<Expr> default_value) {
+  VariableType var_type;
+  if (type_kind) {
+    var_type = *type_kind;
+  } else if (rng_.rand(0, 1) == 0) {
+    var_type = VariableType::Field();
+  } else {
+    var_type = VariableType::Array(rng_.rand(1, cfg_.max_array_len));
+  }
+
+  // 9/10 chance of declaring a variable with a default value.  A caller that asks for
+  // a signal (only the extensions do) gets none: signals cannot take a default.
+  const bool wants_signal = role_kind && role_kind->is_signal;
+  if (!default_value && !var_type.is_array && !wants_signal && rng_.rand(1, 10) != 1) {
+    std::optional<Expr> val = generate_expr(0);
+    if (!val) return std::nullopt;
+    default_value = std::move(val);
+  }
+
+  VariableRole role;
+  if (role_kind) {
+    role = *role_kind;
+  } else if (default_value) {
+    role = VariableRole::Local();  // only locals can take a default value
+  } else if (rng_.rand(0, 1) == 0) {
+    role = rng_.rand(0, 1) == 0 ? VariableRole::Signal(SignalType::Input) : VariableRole::Signal(SignalType::Output);
+  } else {
+    role = VariableRole::Local();
+  }
+
+  // all false even when a default is present (generator.rs:255-260); the extension
+  // makes input signals readable from the start
+  const bool readable = cfg_.inputs_readable && role.is_input();
+  std::vector<bool> initialized(var_type.is_array ? var_type.len : 1, readable);
+
+  std::string name = rng_.rand_string(cfg_.name_len);
+  Variable v = scope_stack_.add_var(std::move(name), var_type, role, std::move(initialized));
+  return Instruction::VarDecl(std::move(v), std::move(default_value));
+}
+
+std::optional<Instruction> Generator::gen_assign() {
+  std::vector<VarRef> vars;
+  for (const Variable* v : scope_stack_.get_scope_vars())
+    if (v->role.is_local() && !v->var_type.is_array) vars.push_back(v->var_ref);
+
+  const VarRef* pick = rng_.rand_vec(vars);
+  if (!pick) return std::nullopt;
+  VarRef var_id = *pick;
+  std::optional<Expr> expr = generate_expr(0);
+  if (!expr) return std::nullopt;
+
+  scope_stack_.mark_initialized(var_id);
+  return Instruction::Assign(var_id, std::move(*expr));
+}
+
+std::optional<Instruction> Generator::gen_array_assign() {
+  std::vector<std::pair<VarRef, size_t>> vars;
+  for (const Variable* v : scope_stack_.get_scope_vars())
+    if (v->role.is_local() && v->var_type.is_array) vars.emplace_back(v->var_ref, v->var_type.len);
+
+  if (const auto* pick = rng_.rand_vec(vars)) {
+    const VarRef var_ref = pick->first;
+    const size_t n = pick->second;
+    std::optional<Expr> expr = generate_expr(0);
+    if (expr) {
+      const size_t idx = rng_.rand(0, n - 1);
+      VarRef marked;
+      marked.id = var_ref.id;
+      marked.idx = idx;
+      scope_stack_.mark_initialized(marked);
+      return Instruction::ArrayAssign(var_ref, Expr::Constant(std::to_string(idx)), std::move(*expr));
+    }
+  }
+  return std::nullopt;
+}
+
+std::optional<Instruction> Generator::gen_constraint() {
+  std::vector<VarRef> vars;
+  for (const Variable* v : scope_stack_.get_scope_vars())
+    if (v->role.is_output() && !v->var_type.is_array && !v->all_initialized()) vars.push_back(v->var_ref);
+
+  if (const VarRef* pick = rng_.rand_vec(vars)) {
+    const VarRef var_id = *pick;
+    // marked before the right-hand side is generated (generator.rs:344-346): `out <== out` is reachable
+    scope_stack_.mark_initialized(var_id);
+    std::optional<Expr> expr = generate_expr(0);
+    if (expr) return Instruction::Constraint(var_id, std::move(*expr));
+  }
+  return std::nullopt;
+}
+
+std::optional<Instruction> Generator::gen_if() {
+  std::optional<Expr> cond = generate_expr(0);
+  if (!cond) return std::nullopt;
+
+  scope_stack_.enter_scope();
+  std::vector<Instruction> then_branch;
+  for (size_t i = 0, n = rng_.rand(1, cfg_.loop_body_max); i < n; i++) push_generated(then_branch, generate_instr());
+  scope_stack_.leave_scope();
+  if (then_branch.empty()) return std::nullopt;
+
+  scope_stack_.enter_scope();
+  std::optional<std::vector<Instruction>> else_branch;
+  if (rng_.rand(0, 1) == 0) {  // an else branch half of the time
+    std::vector<Instruction> instrs;
+    for (size_t i = 0, n = rng_.rand(1, cfg_.loop_body_max); i < n; i++) push_generated(instrs, generate_instr());
+    if (!instrs.empty()) else_branch = std::move(instrs);
+  }
+  scope_stack_.leave_scope();
+  return Instruction::If(std::move(*cond), std::move(then_branch), std::move(else_branch));
+}
+
+std::optional<Instruction> Generator::gen_for() {
+  scope_stack_.enter_scope();
+
+  // the loop always declares a fresh variable with a constant start value
+  const size_t default_value = rng_.rand(0, cfg_.loop_init_max);
+  Instruction init = *gen_var_decl(VariableType::Field(), VariableRole::Local(),
+                                   Expr::Constant(std::to_string(default_value)));
+  const size_t max = rng_.rand(default_value, cfg_.loop_bound_max);
+  const VarRef var_ref = init.var.var_ref;
+
+  Expr cond = Expr::Binary(ExprKind::LessThanEq, Expr::Var(var_ref), Expr::Constant(std::to_string(max)));
+  Instruction step =
+      Instruction::Assign(var_ref, Expr::Binary(ExprKind::Add, Expr::Var(var_ref), Expr::Constant("1")));
+
+  std::vector<Instruction> body;
+  for (size_t i = 0, n = rng_.rand(1, cfg_.loop_body_max); i < n; i++) push_generated(body, generate_instr());
+
+  scope_stack_.leave_scope();
+  if (body.empty()) return std::nullopt;  // the loop variable stays in all_vars, the draws are spent
+  return Instruction::For(std::move(init), std::move(cond), std::move(step), std::move(body));
+}
+
+std::optional<Instruction> Generator::gen_while() {
+  std::optional<Expr> cond = generate_expr(0);
+  if (!cond) return std::nullopt;
+  scope_stack_.enter_scope();
+  std::vector<Instruction> body;
+  for (size_t i = 0, n = rng_.rand(1, cfg_.loop_body_max); i < n; i++) push_generated(body, generate_instr());
+  scope_stack_.leave_scope();
+  if (body.empty()) return std::nullopt;
+  return Instruction::While(std::move(*cond), std::move(body));
+}
+
+std::optional<Expr> Generator::gen_bin_expr(ExprKind k, size_t depth) {
+  std::optional<Expr> left = generate_expr(depth + 1);
+  std::optional<Expr> right = generate_expr(depth + 1);
+  if (!left || !right) return std::nullopt;
+  return Expr::Binary(k, std::move(*left), std::move(*right));
+}
+
+std::optional<Expr> Generator::gen_un_expr(ExprKind k, size_t depth) {
+  std::optional<Expr> e = generate_expr(depth + 1);
+  if (!e) return std::nullopt;
+  return Expr::Unary(k, std::move(*e));
+}
+
+std::optional<Expr> Generator::generate_expr(size_t depth) {
+  // hard limit (generator.rs:486-488)
+  if (depth >= cfg_.max_expr_depth) return Expr::Constant(std::to_string(rng_.next()));
+  // 1/3 chance of stopping early; unreachable at the reference's limit of 1 (generator.rs:490-493)
+  if (depth >= 1 && rng_.rand(1, 3) == 1) return Expr::Constant(std::to_string(rng_.next()));
+
+  const bool has_field_vars =
+      has_vars_of_type([](const Variable& v) { return !v.var_type.is_array && v.all_initialized(); });
+  const bool has_array_vars =
+      has_vars_of_type([](const Variable& v) { return v.var_type.is_array && v.any_initialized(); });
+
+  // the fixed entries of generator.rs:507-531, in order; -1 stands for gen_constant
+  static const int kAll[] = {
+      -1,
+      (int)ExprKind::Add, (int)ExprKind::Sub, (int)ExprKind::Mul, (int)ExprKind::Power, (int)ExprKind::Div,
+      (int)ExprKind::IntDiv, (int)ExprKind::Rem, (int)ExprKind::LessThan, (int)ExprKind::LessThanEq,
+      (int)ExprKind::GreaterThan, (int)ExprKind::GreaterThanEq, (int)ExprKind::Equal, (int)ExprKind::And,
+      (int)ExprKind::Or, (int)ExprKind::BitAnd, (int)ExprKind::BitOr, (int)ExprKind::BitNot, (int)ExprKind::BitXor,
+      (int)ExprKind::BitRShift, (int)ExprKind::BitLShift};
+  static const int kArith[] = {-1, (int)ExprKind::Add, (int)ExprKind::Sub, (int)ExprKind::Mul};
+  const int* table = cfg_.arithmetic_only ? kArith : kAll;
+  const size_t n_fixed = cfg_.arithmetic_only ? sizeof(kArith) / sizeof(int) : sizeof(kAll) / sizeof(int);
+
+  const size_t n_funcs = n_fixed + (has_field_vars ? 1 : 0) + (has_array_vars ? 1 : 0);
+  const size_t idx = rng_.rand(0, n_funcs - 1);
+  if (idx < n_fixed) {
+    const int f = table[idx];
+    if (f < 0) return gen_constant(depth);
+    if ((ExprKind)f == ExprKind::BitNot) return gen_un_expr(ExprKind::BitNot, depth);
+    return gen_bin_expr((ExprKind)f, depth);
+  }
+  if (has_field_vars && idx == n_fixed) return gen_var_ref(depth);
+  return gen_array_index(depth);
+}
+
+std::optional<Expr> Generator::gen_var_ref(size_t) {
+  std::vector<VarRef> vars;
+  for (const Variable* v : scope_stack_.get_scope_vars())
+    if (v->all_initialized() && !v->var_type.is_array) vars.push_back(v->var_ref);
+  const VarRef* pick = rng_.rand_vec(vars);
+  if (!pick) return std::nullopt;
+  return Expr::Var(*pick);
+}
+
+std::optional<Expr> Generator::gen_constant(size_t) { return Expr::Constant(std::to_string(rng_.next())); }
+
+std::optional<Expr> Generator::gen_array_index(size_t) {
+  std::vector<std::pair<VarRef, size_t>> vars;
+  for (const Variable* v : scope_stack_.get_scope_vars()) {
+    if (!v->var_type.is_array || !v->any_initialized()) continue;
+    const std::vector<size_t> indices = v->get_initialized();
+    // a position in 0..=len, not one of `indices` (generator.rs:584): it can name an
+    // unwritten element, or one past the end when every element is written
+    const size_t idx = rng_.rand(0, indices.size());
+    vars.emplace_back(v->var_ref, idx);
+  }
+  if (const auto* pick = rng_.rand_vec(vars)) {
+    VarRef r;
+    r.id = pick->first.id;
+    r.idx = pick->second;
+    return Expr::Var(r);
+  }
+  return std::nullopt;
+}
+
+// ---- extensions (no counterpart in the reference) ----
+
+// a*x + b style term over readable signals and constants: degree <= 1 in the signals
+Expr Generator::gen_linear() {
+  std::vector<VarRef> sigs;
+  for (const Variable* v : scope_stack_.get_scope_vars())
+    if (v->role.is_signal && !v->var_type.is_array && v->all_initialized()) sigs.push_back(v->var_ref);
+  auto term = [&]() -> Expr {
+    if (!sigs.empty() && rng_.rand(0, 3) != 0) return Expr::Var(*rng_.rand_vec(sigs));
+    return Expr::Constant(std::to_string(rng_.next()));
+  };
+  Expr t = term();
+  const uint64_t shape = rng_.rand(0, 2);
+  if (shape == 0) return t;
+  return Expr::Binary(shape == 1 ? ExprKind::Add : ExprKind::Sub, std::move(t), term());
+}
+
+// `fresh output <== lin * lin + lin`: a real rank-1 constraint
+std::optional<Instruction> Generator::gen_constraint_quadratic() {
+  Expr a = gen_linear(), b = gen_linear(), c = gen_linear();
+  auto decl = gen_var_decl(VariableType::Field(), VariableRole::Signal(SignalType::Output), std::nullopt);
+  const VarRef out = decl->var.var_ref;
+  pending_.push_back(std::move(*decl));
+  scope_stack_.mark_initialized(out);
+  Expr rhs = Expr::Binary(ExprKind::Add, Expr::Binary(ExprKind::Mul, std::move(a), std::move(b)), std::move(c));
+  return Instruction::Constraint(out, std::move(rhs));
+}
+
+}  // namespace zkir

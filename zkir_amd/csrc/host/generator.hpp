@@ -1,0 +1,82 @@
+// Random AST producer: the reference's src/generator.rs with its literals lifted
+// into a GeneratorConfig whose defaults are those literals, so the default
+// configuration consumes the random stream draw for draw like the Rust code.
+#pragma once
+#include <optional>
+#include <vector>
+
+#include "../../../include/zkir_hip.h"
+#include "ast.hpp"
+#include "rng.hpp"
+
+namespace zkir {
+
+using GeneratorConfig = zkir_generator_config;
+GeneratorConfig default_generator_config();
+
+class Generator {
+ public:
+  // generator.rs:124-130
+  explicit Generator(Rng rng) : rng_(rng), cfg_(default_generator_config()) {}
+  Generator(Rng rng, const GeneratorConfig& cfg) : rng_(rng), cfg_(cfg) {}
+
+  // generator.rs:142-164.  A Generator is single use, as in the reference.
+  Circuit generate();
+
+  // the two progress lines generate() prints in the reference (generator.rs:148,158)
+  size_t requested() const { return requested_; }
+  size_t generated() const { return generated_; }
+
+  std::optional<Instruction> generate_instr();                        // generator.rs:166-208
+  std::optional<Instruction> gen_var_decl(std::optional<VariableType> type_kind, std::optional<VariableRole> role_kind,
+                                          std::optional<Expr> default_value);  // :214-267
+  std::optional<Instruction> gen_assign();        // :269-289
+  std::optional<Instruction> gen_array_assign();  // :291-327
+  std::optional<Instruction> gen_constraint();    // :329-353
+  std::optional<Instruction> gen_if();            // :355-399 (not dispatched, as in the reference)
+  std::optional<Instruction> gen_for();           // :401-456
+  std::optional<Instruction> gen_while();         // :458-483 (not dispatched)
+  std::optional<Expr> generate_expr(size_t depth);  // :484-543
+  std::optional<Expr> gen_var_ref(size_t depth);    // :545-566
+  std::optional<Expr> gen_constant(size_t depth);   // :568-570
+  std::optional<Expr> gen_array_index(size_t depth);  // :572-601
+
+ private:
+  // generator.rs:30-115
+  struct Scope {
+    std::vector<Variable> vars;
+  };
+  struct ScopeStack {
+    std::vector<Scope> stack;
+    std::vector<Variable> all_vars;
+    size_t next_id = 0;
+    void enter_scope() { stack.emplace_back(); }
+    void leave_scope() { stack.pop_back(); }
+    Variable add_var(std::string name, VariableType t, VariableRole r, std::vector<bool> initialized);
+    std::vector<const Variable*> get_scope_vars() const;
+    void mark_initialized(const VarRef& v);
+  };
+
+  template <class F>
+  bool has_vars_of_type(F pred) const {
+    for (const Variable* v : scope_stack_.get_scope_vars())
+      if (pred(*v)) return true;
+    return false;
+  }
+  std::optional<Instruction> gen_var_decl_default() { return gen_var_decl(std::nullopt, std::nullopt, std::nullopt); }
+  std::optional<Expr> gen_bin_expr(ExprKind k, size_t depth);
+  std::optional<Expr> gen_un_expr(ExprKind k, size_t depth);
+  // extensions
+  std::optional<Instruction> gen_constraint_quadratic();
+  Expr gen_linear();
+  void push_generated(std::vector<Instruction>& out, std::optional<Instruction> instr);
+
+  Rng rng_;
+  GeneratorConfig cfg_;
+  size_t n_instr_ = 0;
+  ScopeStack scope_stack_;
+  std::vector<Instruction> pending_;  // declarations an extension wants emitted before its statement
+  size_t requested_ = 0, generated_ = 0;
+};
+
+}  // namespace zkir

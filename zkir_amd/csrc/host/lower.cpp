@@ -1,0 +1,633 @@
+// See lower.hpp.  Two passes:
+//   1. an abstract interpreter walks the Instruction tree, unrolling loops and
+//      deciding every condition and index from values known at lowering time (the
+//      way circom decides them at compile time), and emits single-assignment ops;
+//   2. a linear scan gives every value a home: the accumulator when its uses
+//      follow immediately, an on-chip (LDS) slot when one is free, else a
+//      device-memory slot; slots are reused once a value is dead.
+#include "lower.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+
+#include "fr_host.hpp"
+
+namespace zkir {
+
+LowerOptions default_lower_options() {
+  LowerOptions o{};
+  o.fold_constants = 1;
+  o.n_lslots = 8;
+  o.reuse_slots = 1;
+  o.max_ops = 0;
+  o.bnot_variant = 0;
+  o.use_acc = 1;
+  return o;
+}
+
+namespace {
+
+// operand of a single-assignment op: >= 0 a value id, < 0 constant ~index
+typedef int32_t Ref;
+constexpr Ref kNoRef = INT32_MIN;
+inline Ref const_ref(uint32_t idx) { return ~(Ref)idx; }
+inline bool is_const(Ref r) { return r < 0 && r != kNoRef; }
+inline uint32_t const_index(Ref r) { return (uint32_t)~r; }
+
+struct SOp {
+  uint8_t code;
+  Ref dst;   // value defined (value ops); output index (OUTPUT); `c` (CHECK)
+  Ref a, b;  // INPUT: a = input element index
+};
+
+enum Degree { kKnown = 0, kLinear = 1, kQuadratic = 2, kNonQuadratic = 3 };
+
+// one term of the linear part of a quadratic value: coef * ref
+struct Term {
+  U256 coef;
+  Ref ref;
+};
+
+struct Val {
+  bool assigned = false;  // false: an output signal nothing has been assigned to yet
+  bool known = false;     // value is fixed at lowering time
+  U256 value;             // when known
+  Ref ref = kNoRef;       // where the tape holds it (may be absent for a folded known value)
+  Degree deg = kKnown;
+  // deg == kQuadratic: value = scale * qa * qb + sum(terms)
+  Ref qa = kNoRef, qb = kNoRef;
+  U256 scale;
+  std::vector<Term> terms;
+};
+
+struct Cells {
+  Variable var;
+  std::vector<Val> cell;
+  size_t io_offset = 0;  // signals: first element in the input / output vector
+  int declared = 0;      // times the declaration has executed
+};
+
+struct U256Hash {
+  size_t operator()(const U256& a) const { return (size_t)(a.w[0] * 0x9e3779b97f4a7c15ull ^ a.w[1] ^ (a.w[2] << 7) ^ a.w[3]); }
+};
+
+class Pass1 {
+ public:
+  Pass1(const Circuit& c, const LowerOptions& o) : circuit_(c), opts_(o) {
+    max_ops_ = o.max_ops ? o.max_ops : (1u << 22);
+  }
+
+  std::vector<SOp> ops;
+  std::vector<U256> consts;
+  int32_t n_values = 0;
+  size_t n_inputs = 0, n_outputs = 0;
+  std::vector<Tape::IoEntry> inputs, outputs;
+
+  void run() {
+    // signal layout: declaration order in circuit.variables, arrays flattened
+    for (const Variable& v : circuit_.variables) {
+      if (vars_.count(v.var_ref.id)) fail(ZKIR_LOWER_BAD_AST, "duplicate variable id");
+      Cells c;
+      c.var = v;
+      const size_t len = v.var_type.is_array ? v.var_type.len : 1;
+      if (v.role.is_input()) {
+        c.io_offset = n_inputs;
+        inputs.push_back({v.var_ref.id, n_inputs, len});
+        n_inputs += len;
+      } else if (v.role.is_output()) {
+        c.io_offset = n_outputs;
+        outputs.push_back({v.var_ref.id, n_outputs, len});
+        n_outputs += len;
+      }
+      vars_[v.var_ref.id] = std::move(c);
+    }
+    output_written_.assign(n_outputs, false);
+    exec_block(circuit_.instructions);
+    // every output element is defined: the ones nothing constrained read as 0
+    for (size_t k = 0; k < n_outputs; k++)
+      if (!output_written_[k]) emit({ZKIR_OP_OUTPUT, (Ref)k, const_of(U256()), kNoRef});
+  }
+
+ private:
+  [[noreturn]] void fail(int32_t cls, const std::string& m) { throw LowerError(cls, m); }
+
+  Ref const_of(const U256& v) {
+    auto it = const_ids_.find(v);
+    if (it != const_ids_.end()) return const_ref(it->second);
+    const uint32_t id = (uint32_t)consts.size();
+    consts.push_back(v);
+    const_ids_[v] = id;
+    return const_ref(id);
+  }
+  void emit(const SOp& op) {
+    if (ops.size() >= max_ops_) fail(ZKIR_LOWER_LOOP_CAP, "tape longer than the op cap");
+    ops.push_back(op);
+  }
+  Ref new_value(uint8_t code, Ref a, Ref b) {
+    const Ref v = n_values++;
+    emit({code, v, a, b});
+    return v;
+  }
+  // the tape operand that holds `v`
+  Ref ref_of(Val& v) {
+    if (v.ref == kNoRef) v.ref = const_of(v.value);
+    return v.ref;
+  }
+  static Val known_val(const U256& x) {
+    Val v;
+    v.assigned = true;
+    v.known = true;
+    v.value = x;
+    return v;
+  }
+
+  Cells& cells_of(const VarRef& r) {
+    auto it = vars_.find(r.id);
+    if (it == vars_.end()) fail(ZKIR_LOWER_BAD_AST, "variable " + std::to_string(r.id) + " not found");
+    return it->second;
+  }
+
+  Val read_var(const VarRef& r) {
+    Cells& c = cells_of(r);
+    if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "variable " + c.var.name + " used before its declaration");
+    size_t k = 0;
+    if (c.var.var_type.is_array) {
+      if (!r.idx) fail(ZKIR_LOWER_BAD_AST, "array " + c.var.name + " referenced without an index");
+      if (*r.idx >= c.cell.size()) fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var.name);
+      k = *r.idx;
+    } else if (r.idx) {
+      fail(ZKIR_LOWER_BAD_AST, "index on the scalar " + c.var.name);
+    }
+    Val& v = c.cell[k];
+    if (!v.assigned) fail(ZKIR_LOWER_UNINIT_SIGNAL, "signal " + c.var.name + " read before it is assigned");
+    if (c.var.role.is_input() && v.ref == kNoRef) {
+      // first read of this input element: load it (and convert it) once
+      const Ref x = n_values++;
+      emit({ZKIR_OP_INPUT, x, (Ref)(c.io_offset + k), kNoRef});
+      v.ref = x;
+    }
+    return v;
+  }
+
+  // ---- expressions ----
+  static uint8_t opcode_of(ExprKind k, uint32_t bnot_variant) {
+    switch (k) {
+      case ExprKind::Add: return ZKIR_OP_ADD;
+      case ExprKind::Sub: return ZKIR_OP_SUB;
+      case ExprKind::Mul: return ZKIR_OP_MUL;
+      case ExprKind::Power: return ZKIR_OP_POW;
+      case ExprKind::Div: return ZKIR_OP_DIV;
+      case ExprKind::IntDiv: return ZKIR_OP_IDIV;
+      case ExprKind::Rem: return ZKIR_OP_REM;
+      case ExprKind::LessThan: return ZKIR_OP_LT;
+      case ExprKind::LessThanEq: return ZKIR_OP_LE;
+      case ExprKind::GreaterThan: return ZKIR_OP_GT;
+      case ExprKind::GreaterThanEq: return ZKIR_OP_GE;
+      case ExprKind::Equal: return ZKIR_OP_EQ;
+      case ExprKind::And: return ZKIR_OP_AND;
+      case ExprKind::Or: return ZKIR_OP_OR;
+      case ExprKind::BitAnd: return ZKIR_OP_BAND;
+      case ExprKind::BitOr: return ZKIR_OP_BOR;
+      case ExprKind::BitXor: return ZKIR_OP_BXOR;
+      case ExprKind::BitRShift: return ZKIR_OP_SHR;
+      case ExprKind::BitLShift: return ZKIR_OP_SHL;
+      case ExprKind::BitNot: return bnot_variant ? ZKIR_OP_BNOT256 : ZKIR_OP_BNOT;
+      default: return ZKIR_OP_NOP;
+    }
+  }
+
+  U256 fold(ExprKind k, const U256& a, const U256& b) {
+    const U256 one = U256::from_u64(1), zero;
+    U256 r;
+    bool ok = true;
+    switch (k) {
+      case ExprKind::Add: return fr::add(a, b);
+      case ExprKind::Sub: return fr::sub(a, b);
+      case ExprKind::Mul: return fr::mul(a, b);
+      case ExprKind::Power: return fr::pow(a, b);
+      case ExprKind::Div: ok = fr::div(a, b, &r); break;
+      case ExprKind::IntDiv: ok = fr::idiv(a, b, &r); break;
+      case ExprKind::Rem: ok = fr::rem(a, b, &r); break;
+      case ExprKind::LessThan: return fr::lt(a, b) ? one : zero;
+      case ExprKind::LessThanEq: return fr::lt(b, a) ? zero : one;
+      case ExprKind::GreaterThan: return fr::lt(b, a) ? one : zero;
+      case ExprKind::GreaterThanEq: return fr::lt(a, b) ? zero : one;
+      case ExprKind::Equal: return a == b ? one : zero;
+      case ExprKind::And: return (!a.is_zero() && !b.is_zero()) ? one : zero;
+      case ExprKind::Or: return (!a.is_zero() || !b.is_zero()) ? one : zero;
+      case ExprKind::BitAnd: return fr::band(a, b);
+      case ExprKind::BitOr: return fr::bor(a, b);
+      case ExprKind::BitXor: return fr::bxor(a, b);
+      case ExprKind::BitRShift: return fr::shr(a, b);
+      case ExprKind::BitLShift: return fr::shl(a, b);
+      case ExprKind::BitNot: return opts_.bnot_variant ? fr::bnot256(a) : fr::bnot254(a);
+      default: fail(ZKIR_LOWER_BAD_AST, "not an operator");
+    }
+    if (!ok) fail(ZKIR_LOWER_DIV_BY_ZERO, "division by a known zero");
+    return r;
+  }
+
+  // the linear part of a value of degree <= 1, as terms
+  std::vector<Term> as_terms(Val& v) {
+    if (v.known && v.value.is_zero()) return {};
+    return {Term{U256::from_u64(1), ref_of(v)}};
+  }
+
+  // degree bookkeeping: circom accepts `<==` only when the right-hand side can be
+  // written A*B + C with A, B, C of degree <= 1 in the signals
+  void combine(ExprKind k, Val& a, Val& b, Val* r) {
+    const Degree da = a.deg, db = b.deg;
+    r->deg = kNonQuadratic;
+    if (k == ExprKind::Add || k == ExprKind::Sub) {
+      if (da <= kLinear && db <= kLinear) {
+        r->deg = kLinear;
+      } else if ((da == kQuadratic && db <= kLinear) || (da <= kLinear && db == kQuadratic)) {
+        Val& q = da == kQuadratic ? a : b;
+        Val& l = da == kQuadratic ? b : a;
+        r->deg = kQuadratic;
+        r->qa = q.qa;
+        r->qb = q.qb;
+        r->scale = q.scale;
+        r->terms = q.terms;
+        std::vector<Term> lt = as_terms(l);
+        if (k == ExprKind::Sub) {
+          if (&q == &b) {  // l - q: negate the quadratic part
+            r->scale = fr::neg(r->scale);
+            for (Term& t : r->terms) t.coef = fr::neg(t.coef);
+          } else {  // q - l
+            for (Term& t : lt) t.coef = fr::neg(t.coef);
+          }
+        }
+        r->terms.insert(r->terms.end(), lt.begin(), lt.end());
+      }
+    } else if (k == ExprKind::Mul) {
+      if (da == kKnown || db == kKnown) {
+        Val& kn = da == kKnown ? a : b;
+        Val& ot = da == kKnown ? b : a;
+        if (ot.deg <= kLinear) {
+          r->deg = ot.deg;  // known * linear stays linear
+        } else if (ot.deg == kQuadratic) {
+          r->deg = kQuadratic;
+          r->qa = ot.qa;
+          r->qb = ot.qb;
+          r->scale = fr::mul(ot.scale, kn.value);
+          r->terms = ot.terms;
+          for (Term& t : r->terms) t.coef = fr::mul(t.coef, kn.value);
+        }
+      } else if (da == kLinear && db == kLinear) {
+        r->deg = kQuadratic;
+        r->qa = ref_of(a);
+        r->qb = ref_of(b);
+        r->scale = U256::from_u64(1);
+      }
+    } else if (k == ExprKind::Div && db == kKnown) {
+      // division by a known non-zero value is multiplication by its inverse
+      U256 inv;
+      if (!fr::div(U256::from_u64(1), b.value, &inv)) fail(ZKIR_LOWER_DIV_BY_ZERO, "division by a known zero");
+      if (da <= kLinear) {
+        r->deg = da;
+      } else if (da == kQuadratic) {
+        r->deg = kQuadratic;
+        r->qa = a.qa;
+        r->qb = a.qb;
+        r->scale = fr::mul(a.scale, inv);
+        r->terms = a.terms;
+        for (Term& t : r->terms) t.coef = fr::mul(t.coef, inv);
+      }
+    }
+    if (r->deg == kKnown) r->deg = kLinear;  // not known: at least one operand depends on a signal
+  }
+
+  Val eval(const Expr& e) {
+    if (++eval_depth_ > 2000) fail(ZKIR_LOWER_BAD_AST, "expression nested too deeply");
+    struct Guard {
+      int& d;
+      ~Guard() { d--; }
+    } guard{eval_depth_};
+    switch (e.kind) {
+      case ExprKind::Constant: {
+        U256 v;
+        if (!fr::parse_decimal(e.constant, &v)) fail(ZKIR_LOWER_BAD_AST, "constant is not a decimal integer: " + e.constant);
+        return known_val(v);
+      }
+      case ExprKind::Var:
+        return read_var(e.var);
+      default:
+        break;
+    }
+    if (!e.left || (e.is_binary() && !e.right)) fail(ZKIR_LOWER_BAD_AST, "operator without operands");
+    Val a = eval(*e.left);
+    Val b = e.is_binary() ? eval(*e.right) : known_val(U256());
+    const uint8_t code = opcode_of(e.kind, opts_.bnot_variant);
+    Val r;
+    r.assigned = true;
+    if (a.known && b.known) {
+      r.known = true;
+      r.deg = kKnown;
+      r.value = fold(e.kind, a.value, b.value);  // also raises division by a known zero
+      if (!opts_.fold_constants) r.ref = new_value(code, ref_of(a), e.is_binary() ? ref_of(b) : kNoRef);
+      return r;
+    }
+    if ((e.kind == ExprKind::Div || e.kind == ExprKind::IntDiv || e.kind == ExprKind::Rem) && b.known &&
+        b.value.is_zero())
+      fail(ZKIR_LOWER_DIV_BY_ZERO, "division by a known zero");
+    combine(e.kind, a, b, &r);
+    r.ref = new_value(code, ref_of(a), e.is_binary() ? ref_of(b) : kNoRef);
+    return r;
+  }
+
+  // ---- statements ----
+  void declare(const Instruction& ins) {
+    Cells& c = cells_of(ins.var.var_ref);
+    const size_t len = c.var.var_type.is_array ? c.var.var_type.len : 1;
+    if (c.var.role.is_signal && c.declared) fail(ZKIR_LOWER_DOUBLE_ASSIGN, "signal " + c.var.name + " declared again by a loop");
+    c.declared++;
+    c.cell.assign(len, Val());
+    if (c.var.role.is_local()) {
+      for (Val& v : c.cell) v = known_val(U256());  // circom variables start at 0
+    } else if (c.var.role.is_input()) {
+      for (Val& v : c.cell) {
+        v.assigned = true;
+        v.deg = kLinear;
+      }
+    }
+    if (ins.default_value) {
+      if (!c.var.role.is_local() || c.var.var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "default value on " + c.var.name);
+      c.cell[0] = eval(*ins.default_value);
+    }
+  }
+
+  void assign(const Instruction& ins) {
+    Cells& c = cells_of(ins.target);
+    if (!c.var.role.is_local() || c.var.var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "Assign target must be a local field");
+    if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "assignment before declaration");
+    c.cell[0] = eval(*ins.value);
+  }
+
+  void array_assign(const Instruction& ins) {
+    Cells& c = cells_of(ins.target);
+    if (!c.var.role.is_local() || !c.var.var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "ArrayAssign target must be a local array");
+    if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "assignment before declaration");
+    Val idx = eval(*ins.index);
+    if (!idx.known) fail(ZKIR_LOWER_UNKNOWN_CONTROL, "array index depends on a signal");
+    if (idx.value.w[1] | idx.value.w[2] | idx.value.w[3] || idx.value.w[0] >= c.cell.size())
+      fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var.name);
+    Val v = eval(*ins.value);
+    cells_of(ins.target).cell[(size_t)idx.value.w[0]] = std::move(v);
+  }
+
+  // sum(coef * ref) as one tape value; kNoRef when there are no terms
+  Ref materialize_terms(const std::vector<Term>& terms) {
+    Ref acc = kNoRef;
+    const U256 one = U256::from_u64(1);
+    for (const Term& t : terms) {
+      if (t.coef.is_zero()) continue;
+      Ref x = t.ref;
+      if (!(t.coef == one)) x = new_value(ZKIR_OP_MUL, const_of(t.coef), x);
+      acc = acc == kNoRef ? x : new_value(ZKIR_OP_ADD, acc, x);
+    }
+    return acc;
+  }
+
+  void constrain(const Instruction& ins) {
+    Cells& c = cells_of(ins.target);
+    if (!c.var.role.is_output()) fail(ZKIR_LOWER_BAD_AST, "Constraint target must be an output signal");
+    if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "constraint before declaration");
+    size_t k = 0;
+    if (c.var.var_type.is_array) {
+      if (!ins.target.idx) fail(ZKIR_LOWER_BAD_AST, "array signal constrained without an index");
+      if (*ins.target.idx >= c.cell.size()) fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var.name);
+      k = *ins.target.idx;
+    }
+    if (c.cell[k].assigned) fail(ZKIR_LOWER_DOUBLE_ASSIGN, "signal " + c.var.name + " assigned twice");
+    Val v = eval(*ins.value);
+    if (v.deg == kNonQuadratic) fail(ZKIR_LOWER_NON_QUADRATIC, "non quadratic constraint on " + c.var.name);
+    // `<==` is `<--` followed by `===`: the signal takes the value, then A*B == C is checked
+    const Ref out = ref_of(v);
+    const size_t out_index = cells_of(ins.target).io_offset + k;
+    emit({ZKIR_OP_OUTPUT, (Ref)out_index, out, kNoRef});
+    output_written_[out_index] = true;
+    const Ref one = const_of(U256::from_u64(1));
+    if (v.deg == kQuadratic) {
+      Ref A = v.qa;
+      if (!(v.scale == U256::from_u64(1))) A = new_value(ZKIR_OP_MUL, const_of(v.scale), A);
+      const Ref lin = materialize_terms(v.terms);
+      const Ref C = lin == kNoRef ? out : new_value(ZKIR_OP_SUB, out, lin);
+      emit({ZKIR_OP_CHECK, C, A, v.qb});
+    } else {
+      emit({ZKIR_OP_CHECK, out, out, one});  // value * 1 == signal
+    }
+    // from here on the signal is a plain degree-1 quantity
+    Val sig;
+    sig.assigned = true;
+    sig.known = v.known;
+    sig.value = v.value;
+    sig.ref = out;
+    sig.deg = v.known ? kKnown : kLinear;
+    cells_of(ins.target).cell[k] = std::move(sig);
+  }
+
+  bool truth(const Expr& cond, const char* what) {
+    Val v = eval(cond);
+    if (!v.known) fail(ZKIR_LOWER_UNKNOWN_CONTROL, std::string(what) + " condition depends on a signal");
+    return !v.value.is_zero();
+  }
+
+  void exec(const Instruction& ins) {
+    switch (ins.kind) {
+      case InstrKind::VarDecl: declare(ins); return;
+      case InstrKind::Assign: assign(ins); return;
+      case InstrKind::ArrayAssign: array_assign(ins); return;
+      case InstrKind::Constraint: constrain(ins); return;
+      case InstrKind::If:
+        if (truth(*ins.cond, "if"))
+          exec_block(ins.then_branch);
+        else if (ins.else_branch)
+          exec_block(*ins.else_branch);
+        return;
+      case InstrKind::For: {
+        if (!ins.init || !ins.step || !ins.cond) fail(ZKIR_LOWER_BAD_AST, "malformed for loop");
+        exec(*ins.init);
+        for (;;) {
+          if (!truth(*ins.cond, "loop")) break;
+          tick();
+          exec_block(ins.body);
+          exec(*ins.step);
+        }
+        return;
+      }
+      case InstrKind::While:
+        while (truth(*ins.cond, "loop")) {
+          tick();
+          exec_block(ins.body);
+        }
+        return;
+    }
+  }
+  void exec_block(const std::vector<Instruction>& b) {
+    if (++block_depth_ > 256) fail(ZKIR_LOWER_BAD_AST, "blocks nested too deeply");
+    for (const Instruction& i : b) exec(i);
+    block_depth_--;
+  }
+  // loop iterations are bounded independently of the ops they emit: a loop whose body
+  // folds to nothing must still stop
+  void tick() {
+    if (++iterations_ > (1u << 20)) fail(ZKIR_LOWER_LOOP_CAP, "more than 2^20 loop iterations");
+  }
+
+  const Circuit& circuit_;
+  LowerOptions opts_;
+  size_t max_ops_;
+  std::unordered_map<size_t, Cells> vars_;
+  std::unordered_map<U256, uint32_t, U256Hash> const_ids_;
+  std::vector<bool> output_written_;
+  uint64_t iterations_ = 0;
+  int eval_depth_ = 0, block_depth_ = 0;
+};
+
+// ---- pass 2: homes for values ----
+struct Home {
+  uint32_t operand = ZKIR_OPERAND_NONE;  // GSLOT / LSLOT operand, or NONE when the value only lives in the accumulator
+};
+
+}  // namespace
+
+Tape Lowerer::lower() {
+  if (opts_.n_lslots > ZKIR_MAX_LSLOTS) throw LowerError(ZKIR_LOWER_BAD_AST, "n_lslots above ZKIR_MAX_LSLOTS");
+  Pass1 p1(circuit, opts_);
+  p1.run();
+  const std::vector<SOp>& ops = p1.ops;
+  const size_t n = ops.size();
+  const int32_t nv = p1.n_values;
+
+  auto defines = [](const SOp& o) { return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP; };
+
+  // last op that reads each value, and whether every read can come from the accumulator:
+  // the accumulator holds value v from its defining op until the next defining op has run
+  std::vector<int64_t> def_at(nv, -1), last_use(nv, -1);
+  std::vector<int64_t> next_def(n + 1, (int64_t)n);  // index of the first defining op at or after i
+  for (int64_t i = (int64_t)n - 1; i >= 0; i--) next_def[i] = defines(ops[i]) ? i : next_def[i + 1];
+  auto note_use = [&](Ref r, int64_t at) {
+    if (r >= 0) last_use[r] = std::max(last_use[r], at);
+  };
+  for (size_t i = 0; i < n; i++) {
+    const SOp& o = ops[i];
+    if (o.code == ZKIR_OP_INPUT) {
+      def_at[o.dst] = (int64_t)i;
+      continue;
+    }
+    note_use(o.a, (int64_t)i);
+    note_use(o.b, (int64_t)i);
+    if (o.code == ZKIR_OP_CHECK) note_use(o.dst, (int64_t)i);
+    if (defines(o)) def_at[o.dst] = (int64_t)i;
+  }
+
+  std::vector<Home> home(nv);
+  std::vector<uint32_t> free_l, free_g;
+  for (uint32_t k = opts_.n_lslots; k-- > 0;) free_l.push_back(k);
+  uint32_t n_g = 0, used_l = 0;
+  // values whose slot is released after op i
+  std::vector<std::vector<int32_t>> dies_at(n);
+  constexpr int64_t kWindowLifetime = 48;  // longer-lived values go to device memory, not the on-chip window
+
+  std::vector<zkir_op> out_ops(n);
+  uint32_t n_checks = 0, n_mul = 0;
+  std::vector<uint32_t> triples;
+
+  auto src_operand = [&](Ref r, size_t at) -> uint32_t {
+    if (r == kNoRef) return ZKIR_OPERAND_NONE;
+    if (is_const(r)) return ZKIR_OPERAND(ZKIR_KIND_CONST, const_index(r));
+    // in the accumulator iff no defining op lies strictly between its definition and this use
+    if (opts_.use_acc && next_def[def_at[r] + 1] >= (int64_t)at) return ZKIR_OPERAND_ACC;
+    if ((home[r].operand >> ZKIR_KIND_SHIFT) == ZKIR_KIND_NONE) throw LowerError(ZKIR_LOWER_BAD_AST, "internal: value has no home");
+    return home[r].operand;
+  };
+
+  for (size_t i = 0; i < n; i++) {
+    const SOp& o = ops[i];
+    zkir_op t{};
+    t.code = o.code;
+    if (o.code == ZKIR_OP_INPUT) {
+      t.a = ZKIR_OPERAND(ZKIR_KIND_INPUT, (uint32_t)o.a);
+      t.b = ZKIR_OPERAND_NONE;
+    } else {
+      t.a = src_operand(o.a, i);
+      t.b = src_operand(o.b, i);
+    }
+    if (o.code == ZKIR_OP_OUTPUT) {
+      t.dst = (uint32_t)o.dst;
+    } else if (o.code == ZKIR_OP_CHECK) {
+      t.dst = src_operand(o.dst, i);
+      triples.push_back(t.a);
+      triples.push_back(t.b);
+      triples.push_back(t.dst);
+      n_checks++;
+    } else {
+      if (o.code == ZKIR_OP_MUL) n_mul++;
+      const int32_t v = o.dst;
+      // does any read fall outside the accumulator's reach?
+      const bool acc_only = opts_.use_acc && last_use[v] < next_def[i + 1] + 1 && last_use[v] <= next_def[i + 1];
+      if (last_use[v] < 0 || acc_only) {
+        t.dst = ZKIR_OPERAND_NONE;
+      } else {
+        const bool window_ok = !free_l.empty() && (last_use[v] - (int64_t)i) <= kWindowLifetime;
+        if (window_ok) {
+          const uint32_t s = free_l.back();
+          free_l.pop_back();
+          used_l = std::max(used_l, s + 1);
+          home[v].operand = ZKIR_OPERAND(ZKIR_KIND_LSLOT, s);
+        } else {
+          uint32_t s;
+          if (!free_g.empty() && opts_.reuse_slots) {
+            s = free_g.back();
+            free_g.pop_back();
+          } else {
+            s = n_g++;
+          }
+          home[v].operand = ZKIR_OPERAND(ZKIR_KIND_GSLOT, s);
+        }
+        t.dst = home[v].operand;
+        if (opts_.reuse_slots) dies_at[(size_t)last_use[v]].push_back(v);
+      }
+    }
+    out_ops[i] = t;
+    // release the slots of values read for the last time by this op; a slot freed here can
+    // be the destination of a LATER op only, never of this one (its store is already placed)
+    for (int32_t v : dies_at[i]) {
+      const uint32_t kind = home[v].operand >> ZKIR_KIND_SHIFT, idx = home[v].operand & ZKIR_INDEX_MASK;
+      if (kind == ZKIR_KIND_LSLOT) free_l.push_back(idx);
+      if (kind == ZKIR_KIND_GSLOT) free_g.push_back(idx);
+    }
+  }
+
+  Tape tape;
+  zkir_tape_hdr& h = tape.hdr;
+  h.magic = ZKIR_TAPE_MAGIC;
+  h.version = ZKIR_TAPE_VERSION;
+  h.n_inputs = (uint32_t)p1.n_inputs;
+  h.n_outputs = (uint32_t)p1.n_outputs;
+  h.n_consts = (uint32_t)p1.consts.size();
+  h.n_ops = (uint32_t)n;
+  h.n_gslots = n_g;
+  h.n_lslots = used_l;
+  h.n_constraints = n_checks;
+  h.n_mul_ops = n_mul;
+  tape.blob.resize(n * sizeof(zkir_op) + p1.consts.size() * 32 + triples.size() * 4);
+  uint8_t* w = tape.blob.data();
+  if (n) std::memcpy(w, out_ops.data(), n * sizeof(zkir_op));
+  w += n * sizeof(zkir_op);
+  for (const U256& c : p1.consts) {
+    uint32_t l[8];
+    c.limbs32(l);
+    std::memcpy(w, l, 32);
+    w += 32;
+  }
+  if (!triples.empty()) std::memcpy(w, triples.data(), triples.size() * 4);
+  tape.inputs = p1.inputs;
+  tape.outputs = p1.outputs;
+  return tape;
+}
+
+}  // namespace zkir
