@@ -170,7 +170,11 @@ typedef struct zkir_generator_config {
   uint32_t quadratic_aware;    /* 1: `<==` right-hand sides are lin*lin+lin   */
   uint32_t forced_inputs;      /* declare this many scalar inputs up front    */
   uint32_t no_loops;           /* 1: never emit For                           */
-  uint32_t reserved[6];
+  uint32_t safe_array_index;   /* 1: array reads name a written element (the
+                                  reference draws a position in 0..=len,
+                                  src/generator.rs:584, which can be unwritten
+                                  or one past the end)                        */
+  uint32_t reserved[5];
 } zkir_generator_config;
 
 int32_t zkir_generator_config_default(zkir_generator_config* cfg);
@@ -225,7 +229,8 @@ typedef struct zkir_lower_options {
   uint32_t max_ops;        /* unrolling cap (0 = 1<<22)                       */
   uint32_t bnot_variant;   /* 0: ZKIR_OP_BNOT, 1: ZKIR_OP_BNOT256             */
   uint32_t use_acc;        /* 1: forward results through ZKIR_KIND_ACC        */
-  uint32_t reserved[2];
+  uint32_t max_iterations; /* loop trips over the whole circuit (0 = 1<<20)   */
+  uint32_t reserved[1];
 } zkir_lower_options;
 
 int32_t zkir_lower_options_default(zkir_lower_options* o);

@@ -76,7 +76,7 @@ class Generator:
         self.loop_init_max, self.loop_bound_max, self.loop_body_max = 30, 60, 5  # :406 :416 :436
         self.name_len = 8  # :264
         self.inputs_readable = self.arithmetic_only = self.quadratic_aware = self.no_loops = 0
-        self.forced_inputs = 0
+        self.forced_inputs = self.safe_array_index = 0
         for k, v in cfg.items():
             assert hasattr(self, k), k
             setattr(self, k, v)
@@ -162,6 +162,8 @@ class Generator:
             role = "local"
         elif self.rng.rand(0, 1) == 0:
             role = "input" if self.rng.rand(0, 1) == 0 else "output"
+            if self.quadratic_aware and role == "output":
+                role = "local"
         else:
             role = "local"
         readable = bool(self.inputs_readable and role == "input")
@@ -256,7 +258,10 @@ class Generator:
             if v["array_len"] is None or not any(v["init"]):
                 continue
             written = [i for i, b in enumerate(v["init"]) if b]
-            vs.append((v["id"], self.rng.rand(0, len(written))))  # a position in 0..=len (:584)
+            idx = self.rng.rand(0, len(written))  # a position in 0..=len (:584)
+            if self.safe_array_index:
+                idx = written[idx % len(written)]
+            vs.append((v["id"], idx))
         pick = self.rng.rand_vec(vs)
         return None if pick is None else ("var", pick[0], pick[1])
 

@@ -1,0 +1,278 @@
+"""Parity of the gfx950 kernels, through the C ABI, against the checkers of oracle/
+(bit-exact: the path is integer arithmetic).  Needs a real MI355X."""
+import json
+import os
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import zkir_amd as z
+from oracle import c_oracle as C
+from oracle import fr_ref as F
+from oracle import zkir_ref as R
+from zkir_amd import api
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+G = lambda i: F.operand(F.K_GSLOT, i)  # noqa: E731
+L = lambda i: F.operand(F.K_LSLOT, i)  # noqa: E731
+K = lambda i: F.operand(F.K_CONST, i)  # noqa: E731
+I = lambda i: F.operand(F.K_INPUT, i)  # noqa: E731
+ACC, NONE = F.operand(F.K_ACC), F.operand(F.K_NONE)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = z.Context(0)
+    yield c
+    c.close()
+
+
+def hand_tape(ops, consts, n_inputs, n_outputs, n_g, n_l):
+    n_con = sum(1 for o in ops if o[0] == F.OP_CHECK)
+    hdr = api.TapeHdr(0x31544B5A, 1, n_inputs, n_outputs, len(consts), len(ops), n_g, n_l, n_con, 0, 0)
+    blob = b"".join(struct.pack("<4I", *o) for o in ops) + b"".join(struct.pack("<8I", *F.limbs32(c)) for c in consts)
+    blob += b"".join(struct.pack("<3I", o[2], o[3], o[1]) for o in ops if o[0] == F.OP_CHECK)
+    return z.Tape.from_parts(hdr, blob)
+
+
+def ext_config(**kw):
+    g = z.default_generator_config()
+    for k, v in kw.items():
+        setattr(g, k, v)
+    return g
+
+
+def random_vectors(rnd, n_inputs, n, special_share=0.25):
+    special = [0, 1, 2, F.P - 1, F.P - 2, F.HALF, F.HALF + 1, (1 << 64) - 1, 1 << 253, 253, 254, 255, F.P - 253, F.P - 254]
+    return [[rnd.choice(special) if rnd.random() < special_share else rnd.randrange(F.P) for _ in range(n_inputs)]
+            for _ in range(n)]
+
+
+def check_against_c_oracle(ctx, tape, vecs):
+    n = len(vecs)
+    inp = z.pack_inputs(vecs, tape.hdr.n_inputs)
+    tid = ctx.upload(tape)
+    out, unsat, first, faults = ctx.eval_batch(tid, inp, n)
+    ctx.release(tid)
+    o_c, u_c, first_c, f_c = C.eval_cpu(bytes(tape.hdr), tape.blob(), inp, n, tape.hdr.n_outputs)
+    assert np.array_equal(out, o_c)
+    assert (unsat, first, faults) == (u_c, first_c, f_c)
+    return out, unsat, first, faults
+
+
+def test_every_operator_against_known_answers(ctx):
+    with open(os.path.join(GOLD, "fr_kat.json")) as f:
+        kat = json.load(f)
+    for name, ent in kat.items():
+        code, rows = ent["code"], ent["rows"]
+        ops = [(F.OP_INPUT, G(0), I(0), NONE), (F.OP_INPUT, L(0), I(1), NONE),
+               (code, G(1), G(0), L(0) if code >= F.OP_ADD else NONE), (F.OP_OUTPUT, 0, G(1), NONE)]
+        tape = hand_tape(ops, [], 2, 1, 2, 1)
+        vecs = [[int(a, 16), int(b, 16)] for a, b, _, _ in rows]
+        tid = ctx.upload(tape)
+        out, unsat, first, faults = ctx.eval_batch(tid, z.pack_inputs(vecs, 2), len(vecs))
+        ctx.release(tid)
+        got = [v[0] for v in z.unpack_outputs(out)]
+        assert got == [int(r, 16) for _, _, r, _ in rows], name
+        assert faults == sum(f for _, _, _, f in rows), name
+        assert unsat == 0 and first is None
+
+
+def test_operand_kinds_and_accumulator(ctx):
+    """Every source / destination kind of the tape format, mixed in one tape."""
+    ops = [(F.OP_INPUT, G(0), I(0), NONE), (F.OP_INPUT, L(0), I(1), NONE),
+           (F.OP_MUL, G(1), G(0), L(0)), (F.OP_OUTPUT, 0, G(1), NONE),
+           (F.OP_ADD, L(1), G(0), L(0)), (F.OP_OUTPUT, 1, ACC, NONE),
+           (F.OP_SUB, NONE, G(0), L(0)), (F.OP_OUTPUT, 2, ACC, NONE),
+           (F.OP_MUL, G(2), ACC, K(0)), (F.OP_OUTPUT, 3, G(2), NONE),
+           (F.OP_CHECK, G(1), G(0), L(0)),  # holds
+           (F.OP_CHECK, G(2), G(0), L(0)),  # almost never holds
+           (F.OP_NEG, G(3), G(0), NONE), (F.OP_OUTPUT, 4, G(3), NONE),
+           (F.OP_COPY, L(2), K(1), NONE), (F.OP_OUTPUT, 5, L(2), NONE),
+           (F.OP_NOP, 0, 0, 0),
+           (F.OP_MUL, NONE, K(1), K(0)), (F.OP_CHECK, ACC, K(1), K(0))]
+    tape = hand_tape(ops, [12345678901234567890123456789 % F.P, F.P - 1], 2, 6, 4, 3)
+    vecs = random_vectors(random.Random(1), 2, 1000)
+    out, unsat, first, faults = check_against_c_oracle(ctx, tape, vecs)
+    for t, v in enumerate(vecs[:50]):
+        o, u, _ = F.eval_tape_one(ops, tape.consts(), v)
+        assert z.unpack_outputs(out[:, :, t:t + 1])[0] == [o[k] for k in range(6)]
+    assert unsat >= 990 and first[0] == 0 and first[1] == 1
+
+
+def test_injected_fault_is_counted_and_located(ctx):
+    """c = a*b for every vector, then one limb of c is flipped in a few vectors."""
+    ops = [(F.OP_INPUT, G(0), I(0), NONE), (F.OP_INPUT, G(1), I(1), NONE), (F.OP_INPUT, G(2), I(2), NONE),
+           (F.OP_CHECK, G(2), G(0), G(1)), (F.OP_CHECK, G(2), G(1), G(0))]
+    tape = hand_tape(ops, [], 3, 0, 3, 0)
+    rnd = random.Random(2)
+    n = 5000
+    vecs = [[a, b, F.mul(a, b)] for a, b in ((rnd.randrange(F.P), rnd.randrange(F.P)) for _ in range(n))]
+    tid = ctx.upload(tape)
+    inp = z.pack_inputs(vecs, 3)
+    _, unsat, first, _ = ctx.eval_batch(tid, inp, n, want_outputs=False)
+    assert unsat == 0 and first is None
+    flipped = sorted(rnd.sample(range(n), 7))
+    for t in flipped:
+        inp[2, rnd.randrange(8), t] ^= 1 << rnd.randrange(29)  # stays below p: limb 7 keeps its top bits
+    _, unsat, first, _ = ctx.eval_batch(tid, inp, n, want_outputs=False)
+    assert unsat == 2 * len(flipped) and first == (flipped[0], 0)
+    ctx.release(tid)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1023])
+def test_batch_sizes_around_the_workgroup(ctx, n):
+    c = z.Generator(11, ext_config(min_instructions=80, max_instructions=80, forced_inputs=3, inputs_readable=1,
+                                   arithmetic_only=1, quadratic_aware=1, no_loops=1, safe_array_index=1)).generate()
+    tape = z.Lowerer(c).lower()
+    check_against_c_oracle(ctx, tape, random_vectors(random.Random(n), tape.hdr.n_inputs, n))
+
+
+def test_empty_batch_and_tape_without_inputs(ctx):
+    txt = '(circuit (vars (var 0 "o" field output (init 0))) (instrs (decl 0) (constrain 0 (pow (const "3") (const "200")))))'
+    o = z.default_lower_options()
+    o.fold_constants = 0
+    tape = z.Lowerer(z.Circuit.parse(txt), o).lower()
+    assert tape.hdr.n_inputs == 0
+    tid = ctx.upload(tape)
+    out, unsat, first, faults = ctx.eval_batch(tid, None, 0)
+    assert out.shape == (1, 8, 0) and unsat == 0 and first is None
+    out, unsat, first, faults = ctx.eval_batch(tid, None, 300)
+    assert all(v == [pow(3, 200, F.P)] for v in z.unpack_outputs(out)) and unsat == 0
+    ctx.release(tid)
+    with pytest.raises(z.ZkirError):
+        ctx.release(tid)  # already released: an error code, not a crash
+
+
+def test_generated_circuits_against_c_oracle(ctx):
+    n_ok = 0
+    for seed in range(1, 40):
+        cfg = dict(min_instructions=150, max_instructions=220, forced_inputs=5, inputs_readable=1, safe_array_index=1,
+                   max_expr_depth=1 + seed % 3, arithmetic_only=seed % 2, quadratic_aware=(seed // 2) % 2,
+                   no_loops=(seed // 4) % 2)
+        c = z.Generator(seed, ext_config(**cfg)).generate()
+        o = z.default_lower_options()
+        o.fold_constants, o.max_iterations, o.n_lslots = seed % 2, 300, [0, 3, 8, 16][seed % 4]
+        o.bnot_variant, o.use_acc, o.reuse_slots = (seed // 8) % 2, (seed // 3) % 2, (seed // 5) % 2
+        try:
+            tape = z.Lowerer(c, o).lower()
+        except z.LowerRejected:
+            continue
+        n_ok += 1
+        check_against_c_oracle(ctx, tape, random_vectors(random.Random(seed), tape.hdr.n_inputs, 300))
+    assert n_ok >= 8
+
+
+def test_reference_shaped_circuits_against_ast_interpreter(ctx):
+    """Circuits exactly as src/generator.rs draws them, every constant expression
+    evaluated on the GPU (fold_constants = 0), against the direct interpretation of the AST."""
+    n_ok = 0
+    for seed in range(1, 400):
+        ref = R.Generator(R.Rng(seed)).generate()
+        o = z.default_lower_options()
+        o.fold_constants, o.max_iterations, o.max_ops = 0, 400, 20000
+        try:
+            tape = z.Lowerer(z.Circuit.parse(R.print_text(ref)), o).lower()
+        except z.LowerRejected:
+            continue
+        n_ok += 1
+        rnd = random.Random(seed)
+        vecs = random_vectors(rnd, tape.hdr.n_inputs, 70)
+        tid = ctx.upload(tape)
+        out, unsat, first, faults = ctx.eval_batch(tid, z.pack_inputs(vecs, tape.hdr.n_inputs), len(vecs))
+        ctx.release(tid)
+        got = z.unpack_outputs(out)
+        for t in (0, 33, 69):
+            it = R.Interpreter(ref, vecs[t], max_iterations=400).run()
+            assert got[t] == it.outputs and it.unsat() == []
+        assert unsat == 0
+    assert n_ok >= 5
+
+
+def test_many_tapes_one_launch(ctx):
+    rnd = random.Random(9)
+    tapes, tids, blocks, want = [], [], [], []
+    n = 130
+    for k in range(14):
+        if k % 5 == 4:  # a tape whose second constraint fails for some vectors
+            ops = [(F.OP_INPUT, G(0), I(0), NONE), (F.OP_INPUT, G(1), I(1), NONE), (F.OP_MUL, G(2), G(0), G(1)),
+                   (F.OP_CHECK, G(2), G(0), G(1)), (F.OP_CHECK, G(0), G(0), G(1))]
+            tape = hand_tape(ops, [], 2, 0, 3, 0)
+        else:
+            cfg = dict(min_instructions=40 + 30 * k, max_instructions=40 + 30 * k, forced_inputs=2 + k % 3,
+                       inputs_readable=1, arithmetic_only=1, quadratic_aware=1, no_loops=1, safe_array_index=1)
+            o = z.default_lower_options()
+            o.n_lslots = [0, 4, 16][k % 3]
+            tape = z.Lowerer(z.Generator(100 + k, ext_config(**cfg)).generate(), o).lower()
+        vecs = random_vectors(rnd, tape.hdr.n_inputs, n, special_share=0.5)
+        inp = z.pack_inputs(vecs, tape.hdr.n_inputs)
+        _, u_c, _, _ = C.eval_cpu(bytes(tape.hdr), tape.blob(), inp, n, tape.hdr.n_outputs, want_outputs=False)
+        tapes.append(tape)
+        tids.append(ctx.upload(tape))
+        blocks.append(inp.reshape(-1))
+        want.append(u_c)
+    unsat, faults = ctx.eval_multi(tids, np.concatenate(blocks), n)
+    assert unsat == want and any(want) and faults == 0
+    assert ctx.eval_multi([], None, n) == ([], 0)
+    for t in tids:
+        ctx.release(t)
+
+
+def test_gadget_chain(ctx):
+    c = z.poseidon_style_gadget(4, 60, 5)
+    tape = z.Lowerer(c).lower()
+    assert tape.hdr.n_constraints == 3 * 4 * 60
+    vecs = random_vectors(random.Random(4), 4, 400)
+    out, unsat, first, faults = check_against_c_oracle(ctx, tape, vecs)
+    assert unsat == 0
+    it = R.Interpreter(R.parse_text(c.text()), vecs[7]).run()
+    assert z.unpack_outputs(out[:, :, 7:8])[0] == it.outputs
+
+
+def test_device_pointer_entry_point_full_size(ctx):
+    """The ~1k-constraint circuit over 2^20 vectors on device buffers: no constraint
+    fails, sampled vectors match the checker, and permuting the batch permutes the outputs."""
+    torch = pytest.importorskip("torch")
+    cfg = dict(min_instructions=4200, max_instructions=4200, forced_inputs=16, inputs_readable=1, arithmetic_only=1,
+               quadratic_aware=1, no_loops=1, safe_array_index=1)
+    tape = z.Lowerer(z.Generator(2024, ext_config(**cfg)).generate()).lower()
+    h = tape.hdr
+    assert 900 <= h.n_constraints <= 1200
+    n = 1 << 20
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    inp = torch.randint(0, 1 << 32, (h.n_inputs, 8, n), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+    inp[:, 7, :] &= 0x0FFFFFFF  # every element below 2^252 < p
+    out = torch.empty((h.n_outputs, 8, n), dtype=torch.int32, device=dev)
+    res = torch.zeros(4, dtype=torch.int64, device=dev)
+    tid = ctx.upload(tape)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.eval_batch_dev(tid, inp.data_ptr(), n, out.data_ptr(), res.data_ptr(), stream)
+    torch.cuda.synchronize()
+    r = res.cpu().numpy().view(np.uint64)
+    assert r[0] == 0 and r[1] == np.uint64(0xFFFFFFFFFFFFFFFF) and r[2] == 0
+    # sampled vectors against the checker
+    idx = torch.cat([torch.arange(0, 300), torch.arange(n // 2 - 150, n // 2 + 150), torch.arange(n - 300, n)]).to(dev)
+    inp_s = inp[:, :, idx].cpu().numpy().view(np.uint32)
+    out_s = out[:, :, idx].cpu().numpy().view(np.uint32)
+    o_c, u_c, _, _ = C.eval_cpu(bytes(h), tape.blob(), np.ascontiguousarray(inp_s), len(idx), h.n_outputs)
+    assert np.array_equal(np.ascontiguousarray(out_s), o_c) and u_c == 0
+    # order of the batch does not matter: reverse the vectors, outputs come out reversed
+    inp_r = torch.flip(inp, dims=[2]).contiguous()
+    out_r = torch.empty_like(out)
+    ctx.eval_batch_dev(tid, inp_r.data_ptr(), n, out_r.data_ptr(), res.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.flip(out_r, dims=[2]), out)
+    ctx.release(tid)
+
+
+def test_measured_rates_are_sane(ctx):
+    mulhi = ctx.int_mul_rate(0)
+    assert 5e12 < mulhi < 6e13
+    fr = ctx.fr_mul_rate()
+    assert 2e10 < fr < 4e11

@@ -1,0 +1,351 @@
+"""Host side of the library (no GPU): the C++ mirror of the reference's rng /
+generator / circom against the committed fixtures and the Python restatement, the
+s-expression form, lower against the direct AST interpreter, and the C ABI's
+error behaviour."""
+import ctypes
+import json
+import os
+import random
+import re
+
+import pytest
+
+import zkir_amd as z
+from oracle import c_oracle as C
+from oracle import fr_ref as F
+from oracle import zkir_ref as R
+from zkir_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def ext_config(**kw):
+    g = z.default_generator_config()
+    for k, v in kw.items():
+        setattr(g, k, v)
+    return g
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "zkir_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(zkir_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 29
+    lib = ctypes.CDLL(api.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_struct_sizes_match_header():
+    assert ctypes.sizeof(api.TapeHdr) == 64
+    assert ctypes.sizeof(api.GeneratorConfig) == 20 * 4
+    assert ctypes.sizeof(api.LowerOptions) == 8 * 4
+
+
+def test_default_config_is_the_reference_literals():
+    g = z.default_generator_config()
+    # src/generator.rs:147, :167, :224, :486, :406, :416, :436, :264
+    assert (g.min_instructions, g.max_instructions, g.statement_budget, g.max_array_len, g.max_expr_depth,
+            g.loop_init_max, g.loop_bound_max, g.loop_body_max, g.name_len) == (15, 30, 10, 10, 1, 30, 60, 5, 8)
+    assert (g.inputs_readable, g.arithmetic_only, g.quadratic_aware, g.forced_inputs, g.no_loops,
+            g.safe_array_index) == (0,) * 6
+
+
+def test_rng_stream_against_fixture():
+    for seed, ent in load("rng_kat.json").items():
+        assert [hex(x) for x in z.rng_stream(int(seed, 16), 16)] == ent["next"]
+    with pytest.raises(z.ZkirError):
+        z.rng_stream(0, 4)  # seed 0 is the xorshift's fixed point
+
+
+def test_generator_and_transpiler_against_fixture():
+    gold = load("circuits.json")
+    for seed, ent in gold["reference"].items():
+        c = z.Generator(int(seed, 16)).generate()
+        assert c.text() == ent["text"]
+        assert z.CircomTranspiler(c).transpile_circuit() == ent["circom"]
+    for seed, ent in gold["extended"].items():
+        c = z.Generator(int(seed, 16), ext_config(**ent["config"])).generate()
+        assert c.text() == ent["text"]
+        assert z.CircomTranspiler(c).transpile_circuit() == ent["circom"]
+
+
+def test_generator_matches_restatement_over_seeds():
+    for seed in list(range(1, 120)) + [2**63, 2**64 - 1]:
+        assert z.Generator(seed).generate().text() == R.print_text(R.Generator(R.Rng(seed)).generate())
+    cfg = dict(min_instructions=40, max_instructions=80, max_expr_depth=3, inputs_readable=1, safe_array_index=1)
+    for seed in range(1, 40):
+        assert z.Generator(seed, ext_config(**cfg)).generate().text() == \
+            R.print_text(R.Generator(R.Rng(seed), **cfg).generate())
+
+
+def test_transpiler_tokens_one_per_operator():
+    """Each Expr variant prints as the Circom token of src/circom.rs:35-157, fully parenthesised."""
+    want = {"add": "+", "sub": "-", "mul": "*", "pow": "**", "div": "/", "idiv": "\\", "rem": "%", "lt": "<",
+            "le": "<=", "gt": ">", "ge": ">=", "eq": "==", "and": "&&", "or": "||", "band": "&", "bor": "|",
+            "bxor": "^", "shr": ">>", "shl": "<<"}
+    for op, tok in want.items():
+        txt = '(circuit (vars (var 0 "x" field local (init 0))) (instrs (decl 0 (%s (const "1") (const "2")))))' % op
+        out = z.CircomTranspiler(z.Circuit.parse(txt)).transpile_circuit()
+        assert out == "\ntemplate Program() {\n   var x = (1%s2);\n}\n\ncomponent main = Program();\n        " % tok
+    txt = '(circuit (vars (var 0 "x" field local (init 0))) (instrs (decl 0 (bnot (const "9")))))'
+    assert "   var x = (~9);\n" in z.CircomTranspiler(z.Circuit.parse(txt)).transpile_circuit()
+
+
+def test_transpiler_statements_by_hand():
+    """if / else, while, for, arrays, signals: the text of src/circom.rs:161-410, written out by hand."""
+    txt = '''(circuit (vars (var 0 "i" field local (init 0)) (var 1 "a" (array 4) local (init 0 0 0 0))
+        (var 2 "inp" (array 2) input (init 0 0)) (var 3 "o" field output (init 0)) (var 4 "w" field local (init 0)))
+      (instrs (decl 1) (decl 2) (decl 3) (decl 4)
+        (for (decl 0 (const "3")) (le (var 0) (const "5")) (assign 0 (add (var 0) (const "1")))
+             (body (aassign 1 (const "2") (var (2 1)))
+                   (if (lt (var 0) (const "4")) (then (assign 4 (const "7"))) (else (assign 4 (const "8")))) ))
+        (while (lt (var 4) (const "9")) (body (assign 4 (add (var 4) (const "1")))))
+        (if (eq (var 4) (const "9")) (then (constrain 3 (var 4))))))'''
+    want = ("\ntemplate Program() {\n"
+            "   var a[4];\n"
+            "   signal input inp[2];\n"
+            "   signal output o;\n"
+            "   var w;\n"
+            "   for (var i = 3; (i<=5); i=(i+1)) {\n"
+            "      a[2]=(inp[1]);\n"
+            "      if ((i<4)) {\n"
+            "         w=7;\n"
+            "      } else {\n"
+            "         w=8;\n"
+            "      }\n"
+            "   }\n"
+            "   while ((w<9)) {\n"
+            "      w=(w+1);\n"
+            "   }\n"
+            "   if ((w==9)) {\n"
+            "      o<==w;\n"
+            "   }\n"
+            "}\n\ncomponent main = Program();\n        ")
+    c = z.Circuit.parse(txt)
+    assert z.CircomTranspiler(c).transpile_circuit() == want
+    assert R.transpile_circuit(R.parse_text(txt)) == want
+    # the asserts of circom.rs:166-175, :203-207 become errors, not aborts
+    bad = '(circuit (vars (var 0 "s" field input (init 0))) (instrs (decl 0) (assign 0 (const "1"))))'
+    with pytest.raises(z.ZkirError):
+        z.CircomTranspiler(z.Circuit.parse(bad)).transpile_circuit()
+
+
+def test_debug_print_is_rust_pretty_debug():
+    txt = '(circuit (vars (var 0 "v" field local (init 0))) (instrs (decl 0 (add (const "1") (var 0))) (assign 0 (var 0))))'
+    want = """[
+    VarDecl(
+        Variable {
+            var_ref: VarRef {
+                id: 0,
+                idx: None,
+            },
+            name: "v",
+            var_type: Field,
+            role: Local,
+            initialized: [
+                false,
+            ],
+        },
+        Some(
+            Add(
+                Constant(
+                    "1",
+                ),
+                Var(
+                    VarRef {
+                        id: 0,
+                        idx: None,
+                    },
+                ),
+            ),
+        ),
+    ),
+    Assign(
+        VarRef {
+            id: 0,
+            idx: None,
+        },
+        Var(
+            VarRef {
+                id: 0,
+                idx: None,
+            },
+        ),
+    ),
+]"""
+    assert z.Circuit.parse(txt).debug() == want
+
+
+def test_text_form_round_trip_and_errors():
+    for seed in range(1, 30):
+        t = z.Generator(seed).generate().text()
+        assert z.Circuit.parse(t).text() == t
+        assert R.print_text(R.parse_text(t)) == t
+    for bad in ["", "(", "(circuit)", "(circuit (vars) (instrs (decl 3)))", "(circuit (vars) (instrs (frob 1)))",
+                '(circuit (vars (var 0 "a" field local (init 0)) (var 0 "b" field local (init 0))) (instrs))',
+                "(circuit (vars) (instrs)) trailing", '(circuit (vars) (instrs (assign 0 (const 5))))']:
+        with pytest.raises(z.ZkirError) as ei:
+            z.Circuit.parse(bad)
+        assert ei.value.code == api.E_INVALID
+
+
+def classify_and_values(circ_text, ref, inputs, fold, bnot=0, cap=2000):
+    o = z.default_lower_options()
+    o.fold_constants, o.max_iterations, o.bnot_variant = fold, cap, bnot
+    try:
+        tape, cls = z.Lowerer(z.Circuit.parse(circ_text), o).lower(), "OK"
+    except z.LowerRejected as e:
+        tape, cls = None, api.LOWER_CLASSES[e.status_class]
+    try:
+        it, rcls = R.Interpreter(ref, inputs, bnot_variant=bnot, max_iterations=cap).run(), "OK"
+    except R.Rejected as e:
+        it, rcls = None, e.cls
+    return tape, cls, it, rcls
+
+
+def n_inputs_of(ref):
+    return sum((v["array_len"] or 1) for v in ref["vars"] if v["role"] == "input")
+
+
+def test_lower_matches_ast_interpreter_reference_shaped():
+    """lower + tape semantics == direct big-integer interpretation of the AST, and the
+    same circuits are refused for the same reason."""
+    seen = set()
+    for seed in range(1, 90):
+        ref = R.Generator(R.Rng(seed)).generate()
+        text = R.print_text(ref)
+        rnd = random.Random(seed)
+        inputs = [rnd.randrange(F.P) for _ in range(n_inputs_of(ref))]
+        for fold in (1, 0):
+            tape, cls, it, rcls = classify_and_values(text, ref, inputs, fold, cap=300)
+            assert cls == rcls, (seed, fold)
+            seen.add(cls)
+            if tape is None:
+                continue
+            outs, unsat, faults = F.eval_tape_one(tape.ops(), tape.consts(), inputs)
+            assert [outs[k] for k in range(tape.hdr.n_outputs)] == it.outputs
+            assert unsat == it.unsat() == [] and tape.hdr.n_constraints == len(it.constraints)
+            assert bool(faults) == bool(it.faults)
+    assert {"OK", "LoopCap", "DoubleAssign"} <= seen
+
+
+EXT = dict(min_instructions=120, max_instructions=160, forced_inputs=6, inputs_readable=1, safe_array_index=1)
+
+
+def test_lower_matches_ast_interpreter_extended():
+    seen = set()
+    for seed in range(1, 60):
+        cfg = dict(EXT, max_expr_depth=1 + seed % 3, arithmetic_only=seed % 2, quadratic_aware=(seed // 2) % 2,
+                   no_loops=(seed // 4) % 2)
+        ref = R.Generator(R.Rng(seed), **cfg).generate()
+        text = R.print_text(ref)
+        assert z.Generator(seed, ext_config(**cfg)).generate().text() == text
+        rnd = random.Random(seed)
+        special = [0, 1, F.P - 1, F.HALF, F.HALF + 1, 2, 253, 254]
+        inputs = [rnd.choice(special) if rnd.random() < 0.3 else rnd.randrange(F.P) for _ in range(n_inputs_of(ref))]
+        for fold, bnot in ((1, 0), (0, 1)):
+            tape, cls, it, rcls = classify_and_values(text, ref, inputs, fold, bnot, cap=400)
+            assert cls == rcls, (seed, fold, cls, rcls)
+            seen.add(cls)
+            if tape is None:
+                continue
+            outs, unsat, faults = F.eval_tape_one(tape.ops(), tape.consts(), inputs)
+            assert [outs[k] for k in range(tape.hdr.n_outputs)] == it.outputs, seed
+            assert unsat == it.unsat() == []
+            assert tape.hdr.n_constraints == len(it.constraints)
+            # the triples table repeats the operands of the CHECK ops, in order
+            checks = [(op[2], op[3], op[1]) for op in tape.ops() if op[0] == F.OP_CHECK]
+            assert checks == tape.triples()
+            # the C interpreter agrees with the big-integer one on the same tape
+            n = 3
+            vecs = [inputs] + [[rnd.randrange(F.P) for _ in inputs] for _ in range(n - 1)]
+            hdr = bytes(tape.hdr)
+            o_c, u_c, first_c, f_c = C.eval_cpu(hdr, tape.blob(), z.pack_inputs(vecs, tape.hdr.n_inputs), n,
+                                                tape.hdr.n_outputs)
+            assert z.unpack_outputs(o_c)[0] == it.outputs and u_c == 0 and first_c is None
+    assert {"OK", "UnknownControl"} <= seen, seen
+
+
+def test_lower_classes_by_hand():
+    base = '''(circuit (vars (var 0 "a" field input (init 0)) (var 1 "b" field input (init 0))
+      (var 2 "o" field output (init 0)) (var 3 "t" field local (init 0)) (var 4 "arr" (array 3) local (init 0 0 0))
+      (var 5 "oo" (array 2) output (init 0 0)))
+     (instrs (decl 0) (decl 1) (decl 2) (decl 3) (decl 4) (decl 5) %s))'''
+    cases = {
+        "OK": '(constrain 2 (add (mul (add (var 0) (const "1")) (var 1)) (const "3")))',
+        "NonQuadratic": '(constrain 2 (lt (var 0) (var 1)))',
+        "DoubleAssign": '(for (decl 3 (const "0")) (le (var 3) (const "1")) (assign 3 (add (var 3) (const "1"))) (body (constrain 2 (var 0))))',
+        "OOBIndex": '(aassign 4 (const "3") (const "1"))',
+        "DivByZero": '(assign 3 (rem (const "4") (const "0")))',
+        "UnknownControl": '(aassign 4 (var 0) (const "1"))',
+        "UninitSignal": '(assign 3 (var (5 1)))',
+        "LoopCap": '(for (decl 3 (const "0")) (le (var 3) (const "5")) (assign 3 (add (var 3) (const "1"))) (body (assign 3 (const "0"))))',
+        "BadAst": '(assign 9 (const "1"))',
+    }
+    for want, stmt in cases.items():
+        text = base % stmt
+        ref = R.parse_text(text)
+        tape, cls, it, rcls = classify_and_values(text, ref, [5, 6], 1, cap=500)
+        assert cls == want and rcls == want, (want, cls, rcls)
+    # division by a known constant keeps the degree (x / k == x * k^-1)
+    text = base % '(constrain 2 (div (mul (var 0) (var 1)) (const "7")))'
+    tape, cls, it, rcls = classify_and_values(text, R.parse_text(text), [5, 6], 1)
+    assert cls == rcls == "OK"
+    outs, unsat, _ = F.eval_tape_one(tape.ops(), tape.consts(), [5, 6])
+    assert outs[0] == F.div(30, 7) == it.outputs[0] and unsat == [] and outs[1] == outs[2] == 0
+
+
+def test_slot_allocation_options_do_not_change_results():
+    cfg = dict(EXT, arithmetic_only=1, quadratic_aware=1, no_loops=1, min_instructions=300, max_instructions=300)
+    c = z.Generator(5, ext_config(**cfg)).generate()
+    rnd = random.Random(1)
+    base = None
+    for nl, reuse, acc in [(0, 0, 0), (0, 1, 0), (4, 1, 1), (8, 1, 1), (16, 1, 1), (16, 0, 1), (1, 1, 1)]:
+        o = z.default_lower_options()
+        o.n_lslots, o.reuse_slots, o.use_acc = nl, reuse, acc
+        t = z.Lowerer(c, o).lower()
+        assert t.hdr.n_lslots <= nl
+        if base is None:
+            inputs = [rnd.randrange(F.P) for _ in range(t.hdr.n_inputs)]
+        res = F.eval_tape_one(t.ops(), t.consts(), inputs)
+        base = base or res
+        assert res == base
+        if not reuse and not nl:
+            assert t.hdr.n_gslots >= 300  # one slot per stored value
+    assert z.Lowerer(c, None).lower().hdr.n_constraints > 20
+
+
+def test_tape_validation_rejects_out_of_range_operands():
+    c = z.Generator(7, ext_config(**dict(EXT, arithmetic_only=1, quadratic_aware=1, no_loops=1))).generate()
+    t = z.Lowerer(c).lower()
+    blob = bytearray(t.blob())
+    z.Tape.from_parts(t.hdr, bytes(blob))  # the untouched tape is accepted
+    import struct
+    for field, value in [(1, F.operand(F.K_GSLOT, t.hdr.n_gslots)), (2, F.operand(F.K_CONST, t.hdr.n_consts)),
+                         (2, F.operand(F.K_LSLOT, 16)), (0, 200)]:
+        b = bytearray(blob)
+        # corrupt the first binary value op
+        k = next(i for i, op in enumerate(t.ops()) if op[0] == F.OP_ADD)
+        struct.pack_into("<I", b, 16 * k + 4 * field, value)
+        with pytest.raises(z.ZkirError):
+            z.Tape.from_parts(t.hdr, bytes(b))
+    with pytest.raises(z.ZkirError):
+        z.Tape.from_parts(t.hdr, bytes(blob[:-4]))
+
+
+def test_gadget_shape():
+    c = z.poseidon_style_gadget(3, 5, 99)
+    t = z.Lowerer(c).lower()
+    assert t.hdr.n_constraints == 3 * 3 * 5 and t.hdr.n_inputs == 3 and t.hdr.n_outputs == 45
+    ref = R.parse_text(c.text())
+    it = R.Interpreter(ref, [1, 2, 3]).run()
+    outs, unsat, _ = F.eval_tape_one(t.ops(), t.consts(), [1, 2, 3])
+    assert [outs[k] for k in range(45)] == it.outputs and unsat == []
+    assert "signal output sq_0_0;" in z.CircomTranspiler(c).transpile_circuit()

@@ -44,12 +44,12 @@ class GeneratorConfig(ctypes.Structure):
     _fields_ = [(n, c_uint32) for n in ("min_instructions", "max_instructions", "statement_budget", "max_array_len",
                                         "max_expr_depth", "loop_init_max", "loop_bound_max", "loop_body_max",
                                         "name_len", "inputs_readable", "arithmetic_only", "quadratic_aware",
-                                        "forced_inputs", "no_loops")] + [("reserved", c_uint32 * 6)]
+                                        "forced_inputs", "no_loops", "safe_array_index")] + [("reserved", c_uint32 * 5)]
 
 
 class LowerOptions(ctypes.Structure):
     _fields_ = [(n, c_uint32) for n in ("fold_constants", "n_lslots", "reuse_slots", "max_ops", "bnot_variant",
-                                        "use_acc")] + [("reserved", c_uint32 * 2)]
+                                        "use_acc", "max_iterations")] + [("reserved", c_uint32 * 1)]
 
 
 def _load():

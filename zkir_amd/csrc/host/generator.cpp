@@ -146,6 +146,9 @@ std::optional<Instruction> Generator::gen_var_decl(std::optional<VariableType> t
     role = VariableRole::Local();  // only locals can take a default value
   } else if (rng_.rand(0, 1) == 0) {
     role = rng_.rand(0, 1) == 0 ? VariableRole::Signal(SignalType::Input) : VariableRole::Signal(SignalType::Output);
+    // extension: when every constraint declares its own output, a free-standing output
+    // could never be constrained; make it a local instead
+    if (cfg_.quadratic_aware && role.is_output()) role = VariableRole::Local();
   } else {
     role = VariableRole::Local();
   }
@@ -331,7 +334,8 @@ std::optional<Expr> Generator::gen_array_index(size_t) {
     const std::vector<size_t> indices = v->get_initialized();
     // a position in 0..=len, not one of `indices` (generator.rs:584): it can name an
     // unwritten element, or one past the end when every element is written
-    const size_t idx = rng_.rand(0, indices.size());
+    size_t idx = rng_.rand(0, indices.size());
+    if (cfg_.safe_array_index) idx = indices[idx % indices.size()];  // extension: always a written element
     vars.emplace_back(v->var_ref, idx);
   }
   if (const auto* pick = rng_.rand_vec(vars)) {

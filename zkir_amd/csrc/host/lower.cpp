@@ -77,6 +77,7 @@ class Pass1 {
  public:
   Pass1(const Circuit& c, const LowerOptions& o) : circuit_(c), opts_(o) {
     max_ops_ = o.max_ops ? o.max_ops : (1u << 22);
+    max_iterations_ = o.max_iterations ? o.max_iterations : (1u << 20);
   }
 
   std::vector<SOp> ops;
@@ -474,12 +475,13 @@ class Pass1 {
   // loop iterations are bounded independently of the ops they emit: a loop whose body
   // folds to nothing must still stop
   void tick() {
-    if (++iterations_ > (1u << 20)) fail(ZKIR_LOWER_LOOP_CAP, "more than 2^20 loop iterations");
+    if (++iterations_ > max_iterations_) fail(ZKIR_LOWER_LOOP_CAP, "loop trip cap exceeded");
   }
 
   const Circuit& circuit_;
   LowerOptions opts_;
   size_t max_ops_;
+  uint64_t max_iterations_;
   std::unordered_map<size_t, Cells> vars_;
   std::unordered_map<U256, uint32_t, U256Hash> const_ids_;
   std::vector<bool> output_written_;
