@@ -55,6 +55,15 @@ class LowerOptions(ctypes.Structure):
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: build it with `python -m zkir_amd.build` (needs hipcc)" % LIB_PATH)
+    # One HIP runtime per process.  PyTorch wheels carry their own libamdhip64 / libhsa-runtime64;
+    # if the system copies were loaded first and torch's second, the second runtime would find no
+    # device.  Importing torch first makes libzkir_hip.so bind to the runtime torch already loaded
+    # (same SONAME), so device pointers and streams of torch tensors can be passed straight in.
+    # Without torch installed the library binds to the system ROCm runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     P = POINTER
     sig = {
