@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: R1CS constraint checks per second over BN254 Fr.
+
+One step = one pass of the hot path (zkir_eval_batch_dev: witness computation, output
+write-back and constraint checks) over one batch of synthetic input vectors that is
+already resident in device memory.  Workload: one generated circuit of about 1k
+quadratic constraints evaluated for 2^20 input vectors per GPU (the second
+configuration of BASELINE.json).  Vectors are independent, so with N GPUs every rank
+evaluates its own 2^20 vectors (weak scaling) and the only communication is one final
+RCCL all-reduce of {unsatisfied pairs, checks done}.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOAD_SEED = 2024
+LOG2_VECTORS = 20
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, datasheet
+MULHI_PEAK_THEORETICAL = 256 * 4 * 16 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock: one v_mul_hi_u32 per lane per clock
+
+
+def workload_tape(z):
+    g = z.default_generator_config()
+    g.min_instructions = g.max_instructions = 4200
+    g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = 16, 1, 1, 1
+    g.no_loops, g.safe_array_index = 1, 1
+    return z.Lowerer(z.Generator(WORKLOAD_SEED, g).generate()).lower()
+
+
+def synthetic_inputs(torch, n_inputs, n, device, seed):
+    """Uniform 252-bit values (every one below p), limb-major SoA [n_inputs][8][n] of uint32."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    x = torch.randint(0, 1 << 32, (n_inputs, 8, n), dtype=torch.int64, device=device, generator=gen).to(torch.int32)
+    x[:, 7, :] &= 0x0FFFFFFF
+    return x.contiguous()
+
+
+def cpu_baseline(tape, inputs_sample, threads):
+    """The scalar C interpreter of oracle/ on the host cores, on a bounded sample."""
+    from oracle import c_oracle
+    n = inputs_sample.shape[2]
+    t0 = time.perf_counter()
+    _, unsat, _, _ = c_oracle.eval_cpu(bytes(tape.hdr), tape.blob(), inputs_sample, n, tape.hdr.n_outputs,
+                                       want_outputs=True, threads=threads)
+    dt = time.perf_counter() - t0
+    assert unsat == 0
+    return tape.hdr.n_constraints * n / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2-vectors", type=int, default=LOG2_VECTORS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import zkir_amd as z
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    tape = workload_tape(z)
+    h = tape.hdr
+    n = 1 << args.log2_vectors
+    ctx = z.Context(local_rank)
+    tid = ctx.upload(tape)
+    inp = synthetic_inputs(torch, h.n_inputs, n, device, 1000 + rank)  # every rank its own vectors
+    out = torch.empty((h.n_outputs, 8, n), dtype=torch.int32, device=device)
+    res = torch.zeros(4, dtype=torch.int64, device=device)
+    totals = torch.zeros(2, dtype=torch.int64, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.eval_batch_dev(tid, inp.data_ptr(), n, out.data_ptr(), res.data_ptr(), stream)
+        totals[0] += res[0]
+        totals[1] += h.n_constraints * n
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    totals.zero_()
+    # per-launch kernel time on the launching stream (HIP events), beside the wall clock
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        ctx.eval_batch_dev(tid, inp.data_ptr(), n, out.data_ptr(), res.data_ptr(), stream)
+        ev[k][1].record()
+        totals[0] += res[0]
+        totals[1] += h.n_constraints * n
+    if world > 1:
+        dist.all_reduce(totals)  # the path's only exchange: mismatch count and checks done
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    unsat_total, checks_total = (int(v) for v in totals.cpu())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+
+    if rank == 0:
+        if world == 1:
+            assert checks_total == h.n_constraints * n * args.steps
+        assert unsat_total == 0, "synthetic witnesses must satisfy every constraint"
+        value = checks_total / elapsed
+        fr_muls = (h.n_mul_ops + h.n_constraints) * n  # per launch: one Montgomery product per Mul op and per check
+        mulhi_peak = ctx.int_mul_rate(0)
+        fr_peak = ctx.fr_mul_rate()
+        achieved = 128.0 * fr_muls / (kernel_ms * 1e-3)
+        alg_bytes = (32 * (h.n_inputs + h.n_outputs) + 4) * n
+        line = {
+            "metric": "R1CS constraint checks/sec over BN254 Fr",
+            "value": value,
+            "unit": "checks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "one generated circuit (extended generator, seed %d) x 2^%d uniform input vectors per GPU; "
+                            "witness + outputs + checks" % (WORKLOAD_SEED, args.log2_vectors),
+                "n_constraints": h.n_constraints, "n_mul_ops": h.n_mul_ops, "n_ops": h.n_ops,
+                "n_inputs": h.n_inputs, "n_outputs": h.n_outputs, "vectors_per_gpu": n,
+                "device_slots": h.n_gslots, "window_slots": h.n_lslots,
+            },
+            "fr_mul_per_s": fr_muls * world / (1e3 * elapsed / args.steps * 1e-3),
+            "roofline": {
+                "kernel": "zkir_interp_kernel",
+                "bound": "int32_mulhi",
+                "achieved": achieved / 1e12,
+                "peak": mulhi_peak / 1e12,
+                "unit": "Tmulhi/s",
+                "frac": achieved / mulhi_peak,
+                "traffic": None,
+                "peak_source": "measured on this device (v_mul_hi_u32 issue-rate probe); theoretical %.1f" % (MULHI_PEAK_THEORETICAL / 1e12),
+                "frac_of_theoretical": achieved / MULHI_PEAK_THEORETICAL,
+                "kernel_ms": kernel_ms,
+                "fr_mul_per_s_kernel": fr_muls / (kernel_ms * 1e-3),
+                "fr_mul_per_s_register_ceiling": fr_peak,
+            },
+            "roofline_hbm": {
+                "bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            sample = 8192 * threads  # a few seconds of work per thread
+            inp_s = np.ascontiguousarray(inp[:, :, :sample].cpu().numpy().view(np.uint32))
+            cps, dt = cpu_baseline(tape, inp_s, threads)
+            line["cpu_baseline"] = {"value": cps, "unit": "checks/s", "cores": threads, "kind": "port",
+                                    "sample": "first %d vectors of the same batch, %d threads, %.1f s" % (sample, threads, dt)}
+        print(json.dumps(line), flush=True)
+    ctx.release(tid)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

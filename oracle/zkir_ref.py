@@ -164,6 +164,8 @@ class Generator:
             role = "input" if self.rng.rand(0, 1) == 0 else "output"
             if self.quadratic_aware and role == "output":
                 role = "local"
+            if self.forced_inputs and role == "input":
+                role = "local"
         else:
             role = "local"
         readable = bool(self.inputs_readable and role == "input")

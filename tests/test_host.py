@@ -318,7 +318,7 @@ def test_slot_allocation_options_do_not_change_results():
         base = base or res
         assert res == base
         if not reuse and not nl:
-            assert t.hdr.n_gslots >= 300  # one slot per stored value
+            assert t.hdr.n_gslots >= 250  # one slot per stored value
     assert z.Lowerer(c, None).lower().hdr.n_constraints > 20
 
 

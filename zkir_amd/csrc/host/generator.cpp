@@ -149,6 +149,8 @@ std::optional<Instruction> Generator::gen_var_decl(std::optional<VariableType> t
     // extension: when every constraint declares its own output, a free-standing output
     // could never be constrained; make it a local instead
     if (cfg_.quadratic_aware && role.is_output()) role = VariableRole::Local();
+    // extension: with a fixed set of up-front inputs, no further inputs appear
+    if (cfg_.forced_inputs && role.is_input()) role = VariableRole::Local();
   } else {
     role = VariableRole::Local();
   }
