@@ -1,0 +1,80 @@
+"""The multi-rank path of the campaign driver on CPU: two gloo ranks shard the circuits
+(i mod 2), evaluate them with the C checker standing in for the GPU, and exchange only
+the final counters and divergent ids; the result must equal a single-rank run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+import zkir_amd as z
+from oracle import c_oracle as C
+from zkir_amd import campaign
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_CIRCUITS, N_VECTORS, BASE_SEED = 24, 16, 99
+
+
+def small_config(cid):
+    g = campaign.campaign_config(cid, min_constraints=4, max_constraints=40)
+    if cid % 5 == 0:  # some circuits keep the reference's loops so lower refuses a few
+        g.no_loops, g.quadratic_aware = 0, 0
+    return g
+
+
+def oracle_evaluate(tapes, n_vectors, ids):
+    """Stand-in for GpuEvaluator in CPU tests: the C checker, plus a planted divergence."""
+    unsat = []
+    for cid, t in zip(ids, tapes):
+        rng = np.random.default_rng(cid)
+        inp = rng.integers(0, 1 << 32, size=(t.hdr.n_inputs, 8, n_vectors), dtype=np.uint64).astype(np.uint32)
+        inp[:, 7, :] &= 0x0FFFFFFF
+        _, u, _, _ = C.eval_cpu(bytes(t.hdr), t.blob(), inp, n_vectors, t.hdr.n_outputs, want_outputs=False)
+        unsat.append(u + (3 if cid % 7 == 3 else 0))
+    return unsat, 0
+
+
+def run_rank(rank, world):
+    o = z.default_lower_options()
+    o.max_iterations = 200
+    res = campaign.run_local(campaign.shard(N_CIRCUITS, rank, world), BASE_SEED, N_VECTORS, oracle_evaluate,
+                             config_of=small_config, lower_options=o, group=5)
+    return res
+
+
+def test_shard_is_a_partition():
+    for world in (1, 2, 3, 8):
+        got = sorted(i for r in range(world) for i in campaign.shard(37, r, world))
+        assert got == list(range(37))
+    assert campaign.circuit_seed(2**64 - 1, 0) != 0 and campaign.circuit_seed(5, 1) == 7
+
+
+def test_two_gloo_ranks_equal_one_rank(tmp_path):
+    single = campaign.reduce_results(run_rank(0, 1))
+    assert single["circuits"] == N_CIRCUITS and single["checks"] > 0
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import sys, json, os\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch.distributed as dist\n"
+        "import test_campaign_cpu as T\n"
+        "from zkir_amd import campaign\n"
+        "dist.init_process_group('gloo')\n"
+        "res = T.run_rank(dist.get_rank(), dist.get_world_size())\n"
+        "tot = campaign.reduce_results(res, dist=dist, capacity=8)\n"
+        "tot['local_circuits'] = res.circuits\n"
+        "open(os.path.join(%r, 'out%%d.json' %% dist.get_rank()), 'w').write(json.dumps(tot))\n"
+        "dist.destroy_process_group()\n" % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    outs = [json.loads((tmp_path / ("out%d.json" % r)).read_text()) for r in range(2)]
+    assert outs[0]["local_circuits"] + outs[1]["local_circuits"] == N_CIRCUITS
+    for o in outs:
+        o.pop("local_circuits")
+        assert o == single  # every rank holds the job-wide totals and the union of divergent ids
+    assert single["unsat"] == 3 * len(single["divergent"]) and len(single["divergent"]) >= 2
+    assert single["rejected"] == sum(single["classes"][1:]) and sum(single["classes"]) == N_CIRCUITS

@@ -1,0 +1,168 @@
+"""Fuzz-campaign driver: many generated circuits, a batch of random input vectors each,
+sharded over the GPUs of a node.
+
+The reference's own driver is `main()` (src/main.rs:81-92): seed, generate, hand the
+circuit to a backend.  A campaign does the same per circuit id, with the seed derived
+from (base seed, circuit id) so any circuit can be regenerated from its id alone.
+
+Sharding: circuit i belongs to rank i mod world; ranks never exchange circuit data.
+The only communication is at the end: one all-reduce of the counters and one
+all-gather of the (padded) lists of divergent circuit ids.
+"""
+import numpy as np
+
+from . import api
+
+
+def circuit_seed(base_seed, circuit_id):
+    """Seed of circuit `circuit_id`: base + id + 1, never 0 (0 is the xorshift's fixed point)."""
+    s = (base_seed + circuit_id + 1) & 0xFFFFFFFFFFFFFFFF
+    return s or 0x9E3779B97F4A7C15
+
+
+def shard(n_circuits, rank, world):
+    """Circuit ids owned by `rank`."""
+    return range(rank, n_circuits, world)
+
+
+def campaign_config(circuit_id, min_constraints=64, max_constraints=4096):
+    """Generator knobs for campaign circuits: straight-line arithmetic circuits whose
+    constraint count is spread log-uniformly over [min, max] by the circuit id."""
+    g = api.default_generator_config()
+    # about one statement in four is a constraint
+    lo, hi = np.log(min_constraints * 4.0), np.log(max_constraints * 4.0)
+    u = ((circuit_id * 2654435761) % 4096) / 4095.0
+    n = int(round(float(np.exp(lo + (hi - lo) * u))))
+    g.min_instructions = g.max_instructions = n
+    g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = 8, 1, 1, 1
+    g.no_loops, g.safe_array_index = 1, 1
+    return g
+
+
+class LocalResult:
+    """What one rank found: counters plus the ids it flags."""
+
+    def __init__(self):
+        self.circuits = 0       # circuits this rank owned
+        self.rejected = 0       # refused by lower (counted per class in `classes`)
+        self.checks = 0         # (vector, constraint) pairs evaluated
+        self.unsat = 0          # pairs that did not hold
+        self.faults = 0         # vectors that divided by zero
+        self.classes = [0] * 9  # ZKIR_LOWER_* histogram
+        self.divergent = []     # circuit ids with unsat pairs, faults, or an unexpected class
+
+
+def run_local(circuit_ids, base_seed, n_vectors, evaluate, config_of=campaign_config, lower_options=None,
+              expected_class=None, group=64):
+    """Generate, lower and evaluate the circuits of one rank.
+
+    evaluate(tapes, n_vectors, circuit_ids) -> (per-tape unsat list, faults) runs a group of
+    lowered tapes for n_vectors fresh random vectors each; on a GPU rank it is
+    GpuEvaluator below.  expected_class maps circuit id -> class name when an external
+    verdict (e.g. circom's) is known; a different class makes the circuit divergent.
+    """
+    res = LocalResult()
+    pending = []
+
+    def flush():
+        if not pending:
+            return
+        ids = [i for i, _ in pending]
+        tapes = [t for _, t in pending]
+        unsat, faults = evaluate(tapes, n_vectors, ids)
+        res.faults += faults
+        for cid, tape, u in zip(ids, tapes, unsat):
+            res.checks += tape.hdr.n_constraints * n_vectors
+            res.unsat += u
+            if u:
+                res.divergent.append(cid)
+        if faults and not any(unsat):
+            res.divergent.extend(ids[:1])  # a fault is reported per launch: flag the group's first circuit
+        pending.clear()
+
+    for cid in circuit_ids:
+        res.circuits += 1
+        circuit = api.Generator(circuit_seed(base_seed, cid), config_of(cid)).generate()
+        cls = 0
+        try:
+            tape = api.Lowerer(circuit, lower_options).lower()
+        except api.LowerRejected as e:
+            cls, tape = e.status_class, None
+        res.classes[cls] += 1
+        if expected_class is not None and cid in expected_class and expected_class[cid] != api.LOWER_CLASSES[cls]:
+            res.divergent.append(cid)
+        if tape is None:
+            res.rejected += 1
+            continue
+        pending.append((cid, tape))
+        if len(pending) >= group:
+            flush()
+    flush()
+    res.divergent = sorted(set(res.divergent))
+    return res
+
+
+class GpuEvaluator:
+    """evaluate() for run_local on one MI355X: inputs are drawn on the device, every
+    group of tapes is one launch (one tape per workgroup pass)."""
+
+    def __init__(self, device_index, input_seed=1):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", device_index)
+        self.ctx = api.Context(device_index)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(input_seed)
+
+    def __call__(self, tapes, n_vectors, circuit_ids):
+        torch = self.torch
+        tids = [self.ctx.upload(t) for t in tapes]
+        words = sum(t.hdr.n_inputs for t in tapes) * 8 * n_vectors
+        inp = torch.randint(0, 1 << 32, (max(words, 1),), dtype=torch.int64, device=self.device,
+                            generator=self.gen).to(torch.int32)
+        # keep every element below p: clear the top 4 bits of limb 7 of each element
+        off = 0
+        for t in tapes:
+            blk = inp[off:off + t.hdr.n_inputs * 8 * n_vectors].view(t.hdr.n_inputs, 8, n_vectors)
+            blk[:, 7, :] &= 0x0FFFFFFF
+            off += t.hdr.n_inputs * 8 * n_vectors
+        unsat = torch.zeros(len(tapes), dtype=torch.int64, device=self.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.ctx.eval_multi_dev(tids, inp.data_ptr(), n_vectors, unsat.data_ptr(), stream)
+        torch.cuda.synchronize()
+        for tid in tids:
+            self.ctx.release(tid)
+        return [int(v) for v in unsat.cpu()], 0
+
+    def close(self):
+        self.ctx.close()
+
+
+def reduce_results(res, dist=None, device=None, capacity=4096):
+    """The campaign's single exchange step.  With torch.distributed initialised (RCCL on
+    GPUs, gloo in the CPU tests) returns the job-wide totals and the sorted union of
+    divergent ids on every rank; without it returns the local values.
+    Ids beyond `capacity` per rank are dropped from the gather (the count still tells)."""
+    import torch
+    counters = [res.circuits, res.rejected, res.checks, res.unsat, res.faults, len(res.divergent)] + list(res.classes)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return {"circuits": res.circuits, "rejected": res.rejected, "checks": res.checks, "unsat": res.unsat,
+                "faults": res.faults, "n_divergent": len(res.divergent), "classes": list(res.classes),
+                "divergent": list(res.divergent)}
+    world = dist.get_world_size()
+    t = torch.tensor(counters, dtype=torch.int64, device=device)
+    dist.all_reduce(t)  # sums: shards are disjoint
+    ids = torch.full((capacity + 1,), -1, dtype=torch.int64, device=device)
+    kept = res.divergent[:capacity]
+    ids[0] = len(kept)  # the count travels first, the payload is padded
+    if kept:
+        ids[1:1 + len(kept)] = torch.tensor(kept, dtype=torch.int64, device=device)
+    gathered = [torch.empty_like(ids) for _ in range(world)]
+    dist.all_gather(gathered, ids)
+    union = []
+    for g in gathered:
+        g = g.cpu()
+        union.extend(int(v) for v in g[1:1 + int(g[0])])
+    tot = [int(v) for v in t.cpu()]
+    return {"circuits": tot[0], "rejected": tot[1], "checks": tot[2], "unsat": tot[3], "faults": tot[4],
+            "n_divergent": tot[5], "classes": tot[6:], "divergent": sorted(set(union))}
