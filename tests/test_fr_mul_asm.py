@@ -13,24 +13,34 @@ INC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 M32 = 0xFFFFFFFF
 
 
-def load_stream():
-    lines = []
+def load_stream(macro="ZKIR_FR_MUL_ASM"):
+    lines, on = [], False
     for raw in open(INC):
+        if raw.startswith("#define"):
+            on = raw.split()[1] == macro
+            continue
         m = re.match(r'\s*"(.*)\\n" \\', raw)
-        if m:
+        if m and on:
             lines.append(m.group(1))
     assert lines, "no instructions parsed"
     return lines
 
 
-def simulate(lines, a, b):
+def simulate(lines, a, b=None):
     reg = {}
-    al, bl, pl = F.limbs32(a), F.limbs32(b), F.limbs32(F.P)
-    for j in range(8):
-        reg["%%%d" % (9 + j)] = al[j]
-        reg["%%%d" % (17 + j)] = bl[j]
-        reg["%%%d" % (25 + j)] = pl[j]
-    reg["%33"] = F.N0_32
+    al, pl = F.limbs32(a), F.limbs32(F.P)
+    if b is not None:  # multiplier operands: a %9.., b %17.., p %25.., np0 %33
+        bl = F.limbs32(b)
+        for j in range(8):
+            reg["%%%d" % (9 + j)] = al[j]
+            reg["%%%d" % (17 + j)] = bl[j]
+            reg["%%%d" % (25 + j)] = pl[j]
+        reg["%33"] = F.N0_32
+    else:  # reduction operands: a %9.., p %17.., np0 %25
+        for j in range(8):
+            reg["%%%d" % (9 + j)] = al[j]
+            reg["%%%d" % (17 + j)] = pl[j]
+        reg["%25"] = F.N0_32
     vcc = 0
 
     def rd(x):
@@ -109,3 +119,12 @@ def test_stream_cost():
     muls = [l for l in valu if l.startswith("v_mad_u64_u32") or l.startswith("v_mul_lo_u32")]
     assert len(muls) == 136  # 2*8*8 multiply-adds + 8 low products
     assert len(valu) <= 300
+
+
+def test_reduction_stream_matches_big_integers():
+    lines = load_stream("ZKIR_FR_REDC_ASM")
+    rnd = random.Random(6)
+    rinv = pow(1 << 256, -1, F.P)
+    for a in [0, 1, 2, F.P - 1, F.HALF, F.R, F.R2, (1 << 253)] + [rnd.randrange(F.P) for _ in range(300)]:
+        assert simulate(lines, a) == (a * rinv) % F.P
+    assert len([l for l in lines if l.startswith("v_")]) <= 160

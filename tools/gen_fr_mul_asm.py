@@ -94,6 +94,40 @@ emit("s_nop 1")
 for j in range(8):
     emit("v_cndmask_b32 %s, %s, %s, vcc" % (R(j), L(j), E(j)))
 
+
+# ---- Montgomery reduction alone: r = a * 2^-256 mod p for a < p (leaving Montgomery form).
+# Same registers; operands: %0..%7 r, %8 carry sink, %9..%16 a, %17..%24 p, %25 np0.
+RA = lambda j: "%%%d" % (9 + j)
+RP = lambda j: "%%%d" % (17 + j)
+RNP = "%25"
+rl = []
+for j in range(8):
+    rl.append("v_mov_b32 %s, 0" % Z(j))
+for j in range(8):
+    rl.append("v_mov_b32 %s, %s" % (E(j), RA(j)))
+rl.append("v_mul_lo_u32 %s, %s, %s" % (M, E(0), RNP))
+for j in range(8):
+    rl.append("v_mad_u64_u32 %s, %%8, %s, %s, %s" % (D(j), M, RP(j), EZ(j)))
+for i in range(8):
+    last = i == 7
+    rl.append("v_add_co_u32 %s, vcc, %s, %s" % (E(0), L(1), H(0)))
+    rl.append("s_nop 0" if last else "v_mul_lo_u32 %s, %s, %s" % (M, E(0), RNP))
+    for j in range(2, 9):
+        if j < 8:
+            rl.append("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (E(j - 1), L(j), H(j - 1)))
+        else:
+            rl.append("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (E(7), H(7)))
+        if not last:
+            rl.append("v_mad_u64_u32 %s, %%8, %s, %s, %s" % (D(j - 2), M, RP(j - 2), EZ(j - 2)))
+        elif j < 8:
+            rl.append("s_nop 0")
+    if not last:
+        rl.append("v_mad_u64_u32 %s, %%8, %s, %s, %s" % (D(7), M, RP(7), EZ(7)))
+# a < p makes the result < p: no final subtraction
+for j in range(8):
+    rl.append("v_mov_b32 %s, %s" % (R(j), E(j)))
+redc_valu = sum(1 for l in rl if l.startswith("v_"))
+
 n_valu = sum(1 for l in lines if l.startswith("v_"))
 n_mad = sum(1 for l in lines if l.startswith("v_mad") or l.startswith("v_mul"))
 with open(OUT, "w") as f:
@@ -103,6 +137,11 @@ with open(OUT, "w") as f:
     f.write("#define ZKIR_FR_MUL_VALU %d\n" % n_valu)
     f.write("#define ZKIR_FR_MUL_ASM \\\n")
     for l in lines:
+        f.write('  "%s\\n" \\\n' % l)
+    f.write("\n")
+    f.write("#define ZKIR_FR_REDC_VALU %d\n" % redc_valu)
+    f.write("#define ZKIR_FR_REDC_ASM \\\n")
+    for l in rl:
         f.write('  "%s\\n" \\\n' % l)
     f.write("\n")
     clob = ", ".join('"v%d"' % (TB + k) for k in range(34))

@@ -128,8 +128,23 @@ __device__ __forceinline__ Fr fr_mul(const Fr& a, const Fr& b) {
   return r;
 }
 
+// a * 2^-256 mod p for a in [0, p): leaves Montgomery form at about half the cost of a product
+__device__ __forceinline__ Fr fr_redc(const Fr& a) {
+  Fr r;
+  uint64_t carry_sink;
+  const uint32_t p0 = ZKIR_P0, p1 = ZKIR_P1, p2 = ZKIR_P2, p3 = ZKIR_P3, p4 = ZKIR_P4, p5 = ZKIR_P5, p6 = ZKIR_P6,
+                 p7 = ZKIR_P7, np = ZKIR_NP0;
+  asm volatile(ZKIR_FR_REDC_ASM
+               : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]),
+                 "=&v"(r.l[6]), "=&v"(r.l[7]), "=&s"(carry_sink)
+               : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]),
+                 "v"(a.l[7]), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7), "s"(np)
+               : ZKIR_FR_MUL_CLOBBERS);
+  return r;
+}
+
 __device__ __forceinline__ Fr fr_to_mont(const Fr& a) { return fr_mul(a, fr_r2()); }
-__device__ __forceinline__ Fr fr_from_mont(const Fr& a) { return fr_mul(a, fr_small(1)); }
+__device__ __forceinline__ Fr fr_from_mont(const Fr& a) { return fr_redc(a); }
 
 // ---- operators that work on the canonical integer (all arguments canonical) ----
 

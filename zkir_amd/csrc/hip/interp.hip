@@ -165,6 +165,9 @@ __device__ __noinline__ SlowResult slow_op(uint32_t code, Fr x, Fr y) {
 // Work item w = (tape, pass): workgroup `blockIdx.x` takes w = blockIdx.x,
 // blockIdx.x + gridDim.x, ... so the grid can be sized to the machine and the
 // per-workgroup slot region is reused from pass to pass.
+// kFull = false is the variant for tapes made only of + - * (and data movement): it
+// carries no call to the out-of-line operators, which keeps its register count down.
+template <bool kFull>
 __global__ void __launch_bounds__(kBlock, 2)
 zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_t passes_per_tape,
                    uint64_t n_vectors,  // vectors per tape
@@ -207,12 +210,14 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
       } else {
         x = load_operand(op.a, acc, cx);
         if (code >= ZKIR_OP_ADD) y = load_operand(op.b, acc, cx);
-        if (code == ZKIR_OP_OUTPUT) y = fr_small(1);
       }
 
       Fr r;
-      if (code == ZKIR_OP_MUL || code == ZKIR_OP_CHECK || code == ZKIR_OP_INPUT || code == ZKIR_OP_OUTPUT) {
+      if (code == ZKIR_OP_MUL || code == ZKIR_OP_CHECK || code == ZKIR_OP_INPUT) {
         r = fr_mul(x, y);
+      } else if (code == ZKIR_OP_OUTPUT) {
+        if (!out) continue;  // nobody wants the outputs: skip the conversion too
+        r = fr_redc(x);
       } else if (code == ZKIR_OP_ADD) {
         r = fr_add(x, y);
       } else if (code == ZKIR_OP_SUB) {
@@ -221,10 +226,12 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
         r = x;
       } else if (code == ZKIR_OP_NEG) {
         r = fr_neg(x);
-      } else {
+      } else if (kFull) {
         const SlowResult sr = slow_op(code, x, y);
         r = sr.r;
         fault |= sr.fault;
+      } else {
+        r = x;  // unreachable: the host only picks this variant for tapes without such ops
       }
 
       if (code == ZKIR_OP_CHECK) {
@@ -234,7 +241,7 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
         if (bad && first_bad == 0xffffffffu) first_bad = check_k;
         check_k++;
       } else if (code == ZKIR_OP_OUTPUT) {
-        if (out && live) {
+        if (live) {
           uint32_t* q = out + (size_t)op.dst * 8 * n_vectors;
 #pragma unroll
           for (int i = 0; i < 8; i++) q[(size_t)i * n_vectors] = r.l[i];
@@ -322,20 +329,35 @@ __global__ void __launch_bounds__(256) zkir_fr_mul_rate_kernel(uint32_t* out, ui
 // ---- host-callable launchers (C++ linkage, used by runtime.cpp) ------------
 namespace zkir {
 
-hipError_t launch_interp(const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape, uint64_t n_vectors,
-                         const uint32_t* inputs, uint32_t* outputs, void* gslot_pool, uint32_t gslots_per_block,
-                         uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats, uint32_t grid, hipStream_t stream) {
+hipError_t launch_interp(bool full, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
+                         uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
+                         uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
+                         uint32_t grid, hipStream_t stream) {
   const size_t lds_bytes = (size_t)lslots * 2 * kBlock * sizeof(uint4);
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS limit the kernel must opt in
-    hipError_t e = hipFuncSetAttribute((const void*)zkir_interp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute(full ? (const void*)zkir_interp_kernel<true> : (const void*)zkir_interp_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(zkir_interp_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, tapes_dev, n_tapes,
-                     passes_per_tape, n_vectors, inputs, outputs, (uint4*)gslot_pool, gslots_per_block, unsat_per_tape,
-                     stats);
+  if (full)
+    hipLaunchKernelGGL(zkir_interp_kernel<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, tapes_dev, n_tapes,
+                       passes_per_tape, n_vectors, inputs, outputs, (uint4*)gslot_pool, gslots_per_block,
+                       unsat_per_tape, stats);
+  else
+    hipLaunchKernelGGL(zkir_interp_kernel<false>, dim3(grid), dim3(kBlock), lds_bytes, stream, tapes_dev, n_tapes,
+                       passes_per_tape, n_vectors, inputs, outputs, (uint4*)gslot_pool, gslots_per_block,
+                       unsat_per_tape, stats);
   return hipGetLastError();
+}
+
+// workgroups of the interpreter that fit on one CU with `lslots` window slots
+hipError_t interp_blocks_per_cu(bool full, uint32_t lslots, int* blocks) {
+  const size_t lds_bytes = (size_t)lslots * 2 * kBlock * sizeof(uint4);
+  hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, zkir_interp_kernel<true>, kBlock, lds_bytes)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, zkir_interp_kernel<false>, kBlock, lds_bytes);
+  if (e == hipSuccess && *blocks < 1) *blocks = 1;
+  return e;
 }
 
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream) {

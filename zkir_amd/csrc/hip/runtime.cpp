@@ -16,9 +16,11 @@
 #include "tape_check.h"
 
 namespace zkir {
-hipError_t launch_interp(const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape, uint64_t n_vectors,
-                         const uint32_t* inputs, uint32_t* outputs, void* gslot_pool, uint32_t gslots_per_block,
-                         uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats, uint32_t grid, hipStream_t stream);
+hipError_t launch_interp(bool full, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
+                         uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
+                         uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
+                         uint32_t grid, hipStream_t stream);
+hipError_t interp_blocks_per_cu(bool full, uint32_t lslots, int* blocks);
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream);
 hipError_t launch_int_mul_rate(int which, uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
 hipError_t launch_fr_mul_rate(uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
@@ -28,6 +30,7 @@ using zkir::TapeDesc;
 
 struct DevTape {
   zkir_tape_hdr hdr{};
+  bool full = false;       // uses an operator beyond + - * : needs the full interpreter
   void* ops = nullptr;     // device
   void* consts = nullptr;  // device, Montgomery form
 };
@@ -82,21 +85,19 @@ int32_t ensure(zkir_ctx* ctx, void** buf, size_t* have, size_t need) {
   return ZKIR_OK;
 }
 
-// Grid: enough workgroups to fill the machine, never more than there is work.
-// The kernel is bounded to 2 waves/SIMD at 256 threads, i.e. up to 2-3 workgroups
-// per CU depending on the LDS window; extra workgroups only queue.
-uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, uint32_t lslots) {
-  uint32_t per_cu = 3;
-  if (lslots > 0) {
-    size_t lds = (size_t)lslots * 2 * ZKIR_BLOCK_THREADS * 16;
-    per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / lds));
-  }
-  uint64_t g = (uint64_t)ctx->n_cu * per_cu;
+// Grid: as many workgroups as the machine holds at once (the occupancy the kernel's
+// registers and the LDS window allow), never more than there is work; each workgroup
+// then walks the work items with a grid stride and reuses its slot region.
+uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, bool full, uint32_t lslots) {
+  int per_cu = 2;
+  if (zkir::interp_blocks_per_cu(full, lslots, &per_cu) != hipSuccess) per_cu = 2;
+  const uint64_t g = (uint64_t)ctx->n_cu * (uint64_t)per_cu;
   return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, work_items));
 }
 
 struct Launch {
   std::vector<TapeDesc> descs;
+  bool full = false;
   uint32_t max_gslots = 0, max_lslots = 0;
 };
 
@@ -119,6 +120,7 @@ int32_t build_launch(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, uint64_
     d.n_constraints = t.hdr.n_constraints;
     in_off += (uint64_t)t.hdr.n_inputs * 8 * N;
     out_off += (uint64_t)t.hdr.n_outputs * 8 * N;
+    L->full = L->full || t.full;
     L->max_gslots = std::max(L->max_gslots, t.hdr.n_gslots);
     L->max_lslots = std::max(L->max_lslots, t.hdr.n_lslots);
   }
@@ -136,7 +138,7 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
   if (rc) return rc;
   const uint32_t passes = (uint32_t)((N + ZKIR_BLOCK_THREADS - 1) / ZKIR_BLOCK_THREADS);
   const uint64_t work = (uint64_t)n * passes;
-  const uint32_t grid = pick_grid(ctx, work, L.max_lslots);
+  const uint32_t grid = pick_grid(ctx, work, L.full, L.max_lslots);
   const size_t slot_bytes = (size_t)2 * ZKIR_BLOCK_THREADS * 16;
   rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, (size_t)grid * L.max_gslots * slot_bytes);
   if (rc) return rc;
@@ -145,7 +147,7 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
   HIP_TRY(ctx, hipMemcpyAsync(ctx->desc_buf, L.descs.data(), (size_t)n * sizeof(TapeDesc), hipMemcpyHostToDevice, stream));
   // L.descs is pageable host memory: hipMemcpyAsync has consumed it when it returns,
   // and the device-side staging buffer is only rewritten by later work on `stream`.
-  hipError_t e = zkir::launch_interp((const TapeDesc*)ctx->desc_buf, n, passes, N, in_dev, out_dev, ctx->gslot_pool,
+  hipError_t e = zkir::launch_interp(L.full, (const TapeDesc*)ctx->desc_buf, n, passes, N, in_dev, out_dev, ctx->gslot_pool,
                                      L.max_gslots, L.max_lslots, unsat_dev, stats_dev, grid, stream);
   if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
   return ZKIR_OK;
@@ -200,6 +202,10 @@ int32_t zkir_tape_upload(zkir_ctx* ctx, const zkir_tape_hdr* hdr, const void* bl
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   DevTape t;
   t.hdr = *hdr;
+  for (uint32_t i = 0; i < hdr->n_ops; i++) {
+    const uint32_t c = ((const zkir_op*)blob)[i].code;
+    if (c == ZKIR_OP_BNOT || c == ZKIR_OP_BNOT256 || (c >= ZKIR_OP_POW && c <= ZKIR_OP_SHL)) t.full = true;
+  }
   const size_t ops_bytes = (size_t)hdr->n_ops * sizeof(zkir_op);
   const size_t consts_bytes = (size_t)hdr->n_consts * 32;
   if (hipMalloc(&t.ops, std::max<size_t>(ops_bytes, 16)) != hipSuccess) return fail(ctx, ZKIR_E_NOMEM, "hipMalloc ops");
