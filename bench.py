@@ -32,7 +32,11 @@ def workload_tape(z):
     g.min_instructions = g.max_instructions = 4200
     g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = 16, 1, 1, 1
     g.no_loops, g.safe_array_index = 1, 1
-    return z.Lowerer(z.Generator(WORKLOAD_SEED, g).generate()).lower()
+    o = z.default_lower_options()
+    for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots"):  # experiment knobs
+        if os.environ.get("ZKIR_BENCH_" + k.upper()):
+            setattr(o, k, int(os.environ["ZKIR_BENCH_" + k.upper()]))
+    return z.Lowerer(z.Generator(WORKLOAD_SEED, g).generate(), o).lower()
 
 
 def synthetic_inputs(torch, n_inputs, n, device, seed):

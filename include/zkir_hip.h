@@ -230,7 +230,9 @@ typedef struct zkir_lower_options {
   uint32_t bnot_variant;   /* 0: ZKIR_OP_BNOT, 1: ZKIR_OP_BNOT256             */
   uint32_t use_acc;        /* 1: forward results through ZKIR_KIND_ACC        */
   uint32_t max_iterations; /* loop trips over the whole circuit (0 = 1<<20)   */
-  uint32_t reserved[1];
+  uint32_t window_lifetime;/* values read for the last time more than this many
+                              ops after their definition go to device memory,
+                              not the on-chip window (0 = 48)                 */
 } zkir_lower_options;
 
 int32_t zkir_lower_options_default(zkir_lower_options* o);

@@ -532,7 +532,7 @@ Tape Lowerer::lower() {
   uint32_t n_g = 0, used_l = 0;
   // values whose slot is released after op i
   std::vector<std::vector<int32_t>> dies_at(n);
-  constexpr int64_t kWindowLifetime = 48;  // longer-lived values go to device memory, not the on-chip window
+  const int64_t kWindowLifetime = opts_.window_lifetime ? opts_.window_lifetime : 48;
 
   std::vector<zkir_op> out_ops(n);
   uint32_t n_checks = 0, n_mul = 0;
