@@ -39,6 +39,15 @@ def workload_tape(z):
     return z.Lowerer(z.Generator(WORKLOAD_SEED, g).generate(), o).lower()
 
 
+def gadget_tape(z, rounds=20834):
+    """configs[4] of BASELINE.json: Poseidon-style chain, width 4, 3*4*rounds constraints."""
+    o = z.default_lower_options()
+    for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots"):
+        if os.environ.get("ZKIR_BENCH_" + k.upper()):
+            setattr(o, k, int(os.environ["ZKIR_BENCH_" + k.upper()]))
+    return z.Lowerer(z.poseidon_style_gadget(4, rounds, 7), o).lower()
+
+
 def synthetic_inputs(torch, n_inputs, n, device, seed):
     """Uniform 252-bit values (every one below p), limb-major SoA [n_inputs][8][n] of uint32."""
     gen = torch.Generator(device=device)
@@ -67,6 +76,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-vectors", type=int, default=LOG2_VECTORS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="config2", choices=["config2", "gadget"],
+                    help="config2 (default, the headline line) or gadget (the deep Poseidon-style chain, "
+                         "2^16 vectors, outputs not requested)")
+    ap.add_argument("--gadget-rounds", type=int, default=20834)
     args = ap.parse_args()
 
     import numpy as np
@@ -85,19 +98,23 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
-    tape = workload_tape(z)
+    gadget = args.workload == "gadget"
+    tape = gadget_tape(z, args.gadget_rounds) if gadget else workload_tape(z)
     h = tape.hdr
+    if gadget and args.log2_vectors == LOG2_VECTORS:
+        args.log2_vectors = 16
     n = 1 << args.log2_vectors
     ctx = z.Context(local_rank)
     tid = ctx.upload(tape)
     inp = synthetic_inputs(torch, h.n_inputs, n, device, 1000 + rank)  # every rank its own vectors
-    out = torch.empty((h.n_outputs, 8, n), dtype=torch.int32, device=device)
+    out = None if gadget else torch.empty((h.n_outputs, 8, n), dtype=torch.int32, device=device)
+    out_ptr = out.data_ptr() if out is not None else None
     res = torch.zeros(4, dtype=torch.int64, device=device)
     totals = torch.zeros(2, dtype=torch.int64, device=device)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        ctx.eval_batch_dev(tid, inp.data_ptr(), n, out.data_ptr(), res.data_ptr(), stream)
+        ctx.eval_batch_dev(tid, inp.data_ptr(), n, out_ptr, res.data_ptr(), stream)
         totals[0] += res[0]
         totals[1] += h.n_constraints * n
 
@@ -116,7 +133,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        ctx.eval_batch_dev(tid, inp.data_ptr(), n, out.data_ptr(), res.data_ptr(), stream)
+        ctx.eval_batch_dev(tid, inp.data_ptr(), n, out_ptr, res.data_ptr(), stream)
         ev[k][1].record()
         totals[0] += res[0]
         totals[1] += h.n_constraints * n
@@ -140,7 +157,7 @@ def main():
         mulhi_peak = ctx.int_mul_rate(0)
         fr_peak = ctx.fr_mul_rate()
         achieved = 128.0 * fr_muls / (kernel_ms * 1e-3)
-        alg_bytes = (32 * (h.n_inputs + h.n_outputs) + 4) * n
+        alg_bytes = (32 * (h.n_inputs + (0 if gadget else h.n_outputs)) + 4) * n
         line = {
             "metric": "R1CS constraint checks/sec over BN254 Fr",
             "value": value,
@@ -155,8 +172,10 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": "one generated circuit (extended generator, seed %d) x 2^%d uniform input vectors per GPU; "
-                            "witness + outputs + checks" % (WORKLOAD_SEED, args.log2_vectors),
+                "workload": ("Poseidon-style gadget chain (width 4, %d rounds) x 2^%d vectors per GPU; witness + checks, "
+                             "outputs not requested" % (args.gadget_rounds, args.log2_vectors)) if gadget else
+                            ("one generated circuit (extended generator, seed %d) x 2^%d uniform input vectors per GPU; "
+                             "witness + outputs + checks" % (WORKLOAD_SEED, args.log2_vectors)),
                 "n_constraints": h.n_constraints, "n_mul_ops": h.n_mul_ops, "n_ops": h.n_ops,
                 "n_inputs": h.n_inputs, "n_outputs": h.n_outputs, "vectors_per_gpu": n,
                 "device_slots": h.n_gslots, "window_slots": h.n_lslots,
@@ -183,7 +202,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
-            sample = 8192 * threads  # a few seconds of work per thread
+            sample = (64 if gadget else 8192) * threads  # a few seconds of work per thread
             inp_s = np.ascontiguousarray(inp[:, :, :sample].cpu().numpy().view(np.uint32))
             cps, dt = cpu_baseline(tape, inp_s, threads)
             line["cpu_baseline"] = {"value": cps, "unit": "checks/s", "cores": threads, "kind": "port",

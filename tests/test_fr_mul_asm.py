@@ -43,7 +43,11 @@ def simulate(lines, a, b=None):
         reg["%25"] = F.N0_32
     vcc = 0
 
+    wrote_output = [False]
+
     def rd(x):
+        # results may share registers with inputs: no input may be read once a result is written
+        assert not (wrote_output[0] and x.startswith("%")), "input %s read after a result was written" % x
         if x in reg:
             return reg[x]
         if re.fullmatch(r"\d+", x):
@@ -70,6 +74,8 @@ def simulate(lines, a, b=None):
         if op == "s_nop":
             n += int(args[0])
             continue
+        if args and re.fullmatch(r"%[0-7]", args[0]):
+            v_ = None  # evaluate sources first, then mark
         if op == "v_mov_b32":
             reg[args[0]] = rd(args[1])
         elif op == "v_mad_u64_u32":
@@ -99,6 +105,8 @@ def simulate(lines, a, b=None):
             reg[args[0]] = rd(args[2]) if vcc else rd(args[1])
         else:
             raise AssertionError("instruction not modelled: " + ins)
+        if args and re.fullmatch(r"%[0-7]", args[0]):
+            wrote_output[0] = True
     return sum(reg["%%%d" % j] << (32 * j) for j in range(8))
 
 

@@ -112,14 +112,16 @@ __device__ __forceinline__ Fr fr_reduce_once(const Fr& x) {
 }
 
 // ---- Montgomery multiplication: a * b * 2^-256 mod p, inputs and result in [0, p) ----
+// The streams write their results with their last eight instructions, after every input
+// register has been read for the last time, so the result may share registers with an input.
 __device__ __forceinline__ Fr fr_mul(const Fr& a, const Fr& b) {
   Fr r;
   uint64_t carry_sink;  // receives the multiply-adds' scalar carry-out; never read
   const uint32_t p0 = ZKIR_P0, p1 = ZKIR_P1, p2 = ZKIR_P2, p3 = ZKIR_P3, p4 = ZKIR_P4, p5 = ZKIR_P5, p6 = ZKIR_P6,
                  p7 = ZKIR_P7, np = ZKIR_NP0;
   asm volatile(ZKIR_FR_MUL_ASM
-               : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]),
-                 "=&v"(r.l[6]), "=&v"(r.l[7]), "=&s"(carry_sink)
+               : "=v"(r.l[0]), "=v"(r.l[1]), "=v"(r.l[2]), "=v"(r.l[3]), "=v"(r.l[4]), "=v"(r.l[5]),
+                 "=v"(r.l[6]), "=v"(r.l[7]), "=&s"(carry_sink)
                : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]),
                  "v"(a.l[7]), "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]),
                  "v"(b.l[6]), "v"(b.l[7]), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7),
@@ -135,8 +137,8 @@ __device__ __forceinline__ Fr fr_redc(const Fr& a) {
   const uint32_t p0 = ZKIR_P0, p1 = ZKIR_P1, p2 = ZKIR_P2, p3 = ZKIR_P3, p4 = ZKIR_P4, p5 = ZKIR_P5, p6 = ZKIR_P6,
                  p7 = ZKIR_P7, np = ZKIR_NP0;
   asm volatile(ZKIR_FR_REDC_ASM
-               : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]),
-                 "=&v"(r.l[6]), "=&v"(r.l[7]), "=&s"(carry_sink)
+               : "=v"(r.l[0]), "=v"(r.l[1]), "=v"(r.l[2]), "=v"(r.l[3]), "=v"(r.l[4]), "=v"(r.l[5]),
+                 "=v"(r.l[6]), "=v"(r.l[7]), "=&s"(carry_sink)
                : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]),
                  "v"(a.l[7]), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7), "s"(np)
                : ZKIR_FR_MUL_CLOBBERS);

@@ -196,59 +196,96 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
     uint32_t fault = 0, first_bad = 0xffffffffu, check_k = 0;
     uint64_t wave_unsat = 0;
 
+    // Every value-defining op leaves its result in `acc` (and stores it if the tape asks);
+    // CHECK and OUTPUT leave `acc` alone.  The next op is fetched (scalar load) while the
+    // current one runs.  An operand of kind ACC is used in place: the multiplier and the
+    // adder read `acc` directly and may write their result over it.
+    zkir_op next_op = ops[0];
     for (uint32_t pc = 0; pc < td.n_ops; pc++) {
-      const zkir_op op = ops[pc];
+      const zkir_op op = next_op;
+      if (pc + 1 < td.n_ops) next_op = ops[pc + 1];
       const uint32_t code = op.code & 0xffu;
-      Fr x, y = fr_zero();
-      if (code == ZKIR_OP_INPUT) {
-        const uint32_t* q = in + (size_t)(op.a & ZKIR_INDEX_MASK) * 8 * n_vectors;
-#pragma unroll
-        for (int i = 0; i < 8; i++) x.l[i] = q[(size_t)i * n_vectors];
-        y = fr_r2();
-      } else if (code == ZKIR_OP_NOP) {
-        continue;
-      } else {
-        x = load_operand(op.a, acc, cx);
-        if (code >= ZKIR_OP_ADD) y = load_operand(op.b, acc, cx);
-      }
+      const bool a_acc = (op.a >> ZKIR_KIND_SHIFT) == ZKIR_KIND_ACC;
+      const bool b_acc = (op.b >> ZKIR_KIND_SHIFT) == ZKIR_KIND_ACC;
 
-      Fr r;
-      if (code == ZKIR_OP_MUL || code == ZKIR_OP_CHECK || code == ZKIR_OP_INPUT) {
-        r = fr_mul(x, y);
-      } else if (code == ZKIR_OP_OUTPUT) {
-        if (!out) continue;  // nobody wants the outputs: skip the conversion too
-        r = fr_redc(x);
+      if (code == ZKIR_OP_MUL) {
+        if (a_acc) {
+          const Fr y = load_operand(op.b, acc, cx);
+          acc = fr_mul(acc, y);
+        } else {
+          const Fr x = load_operand(op.a, acc, cx);
+          const Fr y = load_operand(op.b, acc, cx);
+          acc = fr_mul(x, y);
+        }
+        store_operand(op.dst, acc, cx);
       } else if (code == ZKIR_OP_ADD) {
-        r = fr_add(x, y);
+        if (a_acc) {
+          const Fr y = load_operand(op.b, acc, cx);
+          acc = fr_add(acc, y);
+        } else {
+          const Fr x = load_operand(op.a, acc, cx);
+          const Fr y = load_operand(op.b, acc, cx);
+          acc = fr_add(x, y);
+        }
+        store_operand(op.dst, acc, cx);
       } else if (code == ZKIR_OP_SUB) {
-        r = fr_sub(x, y);
-      } else if (code == ZKIR_OP_COPY) {
-        r = x;
-      } else if (code == ZKIR_OP_NEG) {
-        r = fr_neg(x);
-      } else if (kFull) {
-        const SlowResult sr = slow_op(code, x, y);
-        r = sr.r;
-        fault |= sr.fault;
-      } else {
-        r = x;  // unreachable: the host only picks this variant for tapes without such ops
-      }
-
-      if (code == ZKIR_OP_CHECK) {
+        if (a_acc) {
+          const Fr y = load_operand(op.b, acc, cx);
+          acc = fr_sub(acc, y);
+        } else if (b_acc) {
+          const Fr x = load_operand(op.a, acc, cx);
+          acc = fr_sub(x, acc);
+        } else {
+          const Fr x = load_operand(op.a, acc, cx);
+          const Fr y = load_operand(op.b, acc, cx);
+          acc = fr_sub(x, y);
+        }
+        store_operand(op.dst, acc, cx);
+      } else if (code == ZKIR_OP_CHECK) {
+        Fr t;
+        if (a_acc) {
+          const Fr y = load_operand(op.b, acc, cx);
+          t = fr_mul(acc, y);
+        } else {
+          const Fr x = load_operand(op.a, acc, cx);
+          const Fr y = load_operand(op.b, acc, cx);
+          t = fr_mul(x, y);
+        }
         const Fr c = load_operand(op.dst, acc, cx);
-        const bool bad = live && !u256_eq(r, c);
+        const bool bad = live && !u256_eq(t, c);
         wave_unsat += __popcll(__ballot(bad));
         if (bad && first_bad == 0xffffffffu) first_bad = check_k;
         check_k++;
       } else if (code == ZKIR_OP_OUTPUT) {
-        if (live) {
-          uint32_t* q = out + (size_t)op.dst * 8 * n_vectors;
+        if (out) {  // nobody wants the outputs: skip the conversion too
+          const Fr x = load_operand(op.a, acc, cx);
+          const Fr r = fr_redc(x);
+          if (live) {
+            uint32_t* q = out + (size_t)op.dst * 8 * n_vectors;
 #pragma unroll
-          for (int i = 0; i < 8; i++) q[(size_t)i * n_vectors] = r.l[i];
+            for (int i = 0; i < 8; i++) q[(size_t)i * n_vectors] = r.l[i];
+          }
         }
-      } else {
-        acc = r;
-        store_operand(op.dst, r, cx);
+      } else if (code == ZKIR_OP_INPUT) {
+        const uint32_t* q = in + (size_t)(op.a & ZKIR_INDEX_MASK) * 8 * n_vectors;
+        Fr x;
+#pragma unroll
+        for (int i = 0; i < 8; i++) x.l[i] = q[(size_t)i * n_vectors];
+        acc = fr_mul(x, fr_r2());
+        store_operand(op.dst, acc, cx);
+      } else if (code == ZKIR_OP_COPY) {
+        acc = load_operand(op.a, acc, cx);
+        store_operand(op.dst, acc, cx);
+      } else if (code == ZKIR_OP_NEG) {
+        acc = fr_neg(load_operand(op.a, acc, cx));
+        store_operand(op.dst, acc, cx);
+      } else if (kFull && code != ZKIR_OP_NOP) {
+        const Fr x = load_operand(op.a, acc, cx);
+        const Fr y = code >= ZKIR_OP_ADD ? load_operand(op.b, acc, cx) : fr_zero();
+        const SlowResult sr = slow_op(code, x, y);
+        acc = sr.r;
+        fault |= sr.fault;
+        store_operand(op.dst, acc, cx);
       }
     }
 

@@ -558,6 +558,11 @@ Tape Lowerer::lower() {
       t.a = src_operand(o.a, i);
       t.b = src_operand(o.b, i);
     }
+    // commutative ops take the accumulator as their first operand: the kernel then
+    // multiplies / adds in place instead of copying it
+    if ((o.code == ZKIR_OP_MUL || o.code == ZKIR_OP_ADD || o.code == ZKIR_OP_CHECK) &&
+        (t.b >> ZKIR_KIND_SHIFT) == ZKIR_KIND_ACC && (t.a >> ZKIR_KIND_SHIFT) != ZKIR_KIND_ACC)
+      std::swap(t.a, t.b);
     if (o.code == ZKIR_OP_OUTPUT) {
       t.dst = (uint32_t)o.dst;
     } else if (o.code == ZKIR_OP_CHECK) {
