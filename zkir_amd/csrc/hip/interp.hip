@@ -34,6 +34,21 @@ typedef const ZKIR_UNIFORM TapeDesc* uniform_desc_t;
 // limbs 0..3 at plane 0, limbs 4..7 at plane 1.  Consecutive lanes are 16 bytes
 // apart, so every access is one 128-bit instruction per plane: conflict-free
 // in LDS, fully coalesced in device memory.
+// The LDS window is addressed through the array itself, never through a pointer kept in a
+// struct: a pointer would decay to the generic address space and every access would become a
+// flat_load / flat_store instead of ds_read_b128 / ds_write_b128.
+extern __shared__ uint4 zkir_lds_slots[];
+__device__ __forceinline__ Fr load_lds_slot(uint32_t slot) {
+  const uint32_t i = slot * 2 * kBlock + threadIdx.x;
+  const uint4 lo = zkir_lds_slots[i], hi = zkir_lds_slots[i + kBlock];
+  return Fr{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+}
+__device__ __forceinline__ void store_lds_slot(uint32_t slot, const Fr& v) {
+  const uint32_t i = slot * 2 * kBlock + threadIdx.x;
+  zkir_lds_slots[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  zkir_lds_slots[i + kBlock] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
 __device__ __forceinline__ Fr load_slot(const uint4* base, uint32_t slot) {
   const uint4* p = base + (size_t)slot * 2 * kBlock + threadIdx.x;
   uint4 lo = p[0], hi = p[kBlock];
@@ -46,15 +61,14 @@ __device__ __forceinline__ void store_slot(uint4* base, uint32_t slot, const Fr&
 }
 
 struct LaneCtx {
-  uint4* gslots;        // this workgroup's device-memory slots
-  uint4* lslots;        // this workgroup's LDS slots
+  uint4* gslots;         // this workgroup's device-memory slots
   uniform_u32_t consts;  // Montgomery-form constant pool of the tape
 };
 
 __device__ __forceinline__ Fr load_operand(uint32_t o, const Fr& acc, const LaneCtx& cx) {
   const uint32_t kind = o >> ZKIR_KIND_SHIFT, idx = o & ZKIR_INDEX_MASK;
   if (kind == ZKIR_KIND_ACC) return acc;
-  if (kind == ZKIR_KIND_LSLOT) return load_slot(cx.lslots, idx);
+  if (kind == ZKIR_KIND_LSLOT) return load_lds_slot(idx);
   if (kind == ZKIR_KIND_CONST) {
     uniform_u32_t c = cx.consts + (size_t)idx * 8;
     return Fr{{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]}};
@@ -64,7 +78,7 @@ __device__ __forceinline__ Fr load_operand(uint32_t o, const Fr& acc, const Lane
 __device__ __forceinline__ void store_operand(uint32_t o, const Fr& v, const LaneCtx& cx) {
   const uint32_t kind = o >> ZKIR_KIND_SHIFT, idx = o & ZKIR_INDEX_MASK;
   if (kind == ZKIR_KIND_LSLOT)
-    store_slot(cx.lslots, idx, v);
+    store_lds_slot(idx, v);
   else if (kind == ZKIR_KIND_GSLOT)
     store_slot(cx.gslots, idx, v);
 }
@@ -162,9 +176,10 @@ __device__ __noinline__ SlowResult slow_op(uint32_t code, Fr x, Fr y) {
 }
 
 // ---- the interpreter ------------------------------------------------------
-// Work item w = (tape, pass): workgroup `blockIdx.x` takes w = blockIdx.x,
-// blockIdx.x + gridDim.x, ... so the grid can be sized to the machine and the
-// per-workgroup slot region is reused from pass to pass.
+// Work item w = (tape, pass).  Workgroups draw items from one device-wide counter (zeroed
+// by the host before the launch) until it runs past the last item, so the grid can be sized
+// to the machine, the per-workgroup slot region is reused from item to item, and a
+// workgroup that starts late (grid larger than what is resident) just finds less work left.
 // kFull = false is the variant for tapes made only of + - * (and data movement): it
 // carries no call to the out-of-line operators, which keeps its register count down.
 template <bool kFull>
@@ -173,14 +188,19 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
                    uint64_t n_vectors,  // vectors per tape
                    const uint32_t* __restrict__ inputs, uint32_t* __restrict__ outputs,
                    uint4* __restrict__ gslot_pool, uint32_t gslots_per_block,
-                   uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats) {
-  extern __shared__ uint4 lds_slots[];
+                   uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats,
+                   uint32_t* __restrict__ work_counter) {
+  __shared__ uint32_t next_item;
   LaneCtx cx;
-  cx.lslots = lds_slots;
   cx.gslots = gslot_pool + (size_t)blockIdx.x * gslots_per_block * 2 * kBlock;
 
-  const uint64_t total = (uint64_t)n_tapes * passes_per_tape;
-  for (uint64_t w = blockIdx.x; w < total; w += gridDim.x) {
+  const uint64_t total = (uint64_t)n_tapes * passes_per_tape;  // the host keeps this below 2^32
+  for (;;) {
+    if (threadIdx.x == 0) next_item = atomicAdd(work_counter, 1u);
+    __syncthreads();
+    const uint64_t w = next_item;
+    __syncthreads();  // everyone has read it before lane 0 draws again
+    if (w >= total) break;
     const uint32_t tape_i = (uint32_t)(w / passes_per_tape);
     const uint32_t pass = (uint32_t)(w % passes_per_tape);
     const TapeDesc td = ((uniform_desc_t)tapes)[tape_i];
@@ -369,7 +389,7 @@ namespace zkir {
 hipError_t launch_interp(bool full, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
-                         uint32_t grid, hipStream_t stream) {
+                         uint32_t* work_counter, uint32_t grid, hipStream_t stream) {
   const size_t lds_bytes = (size_t)lslots * 2 * kBlock * sizeof(uint4);
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS limit the kernel must opt in
@@ -380,11 +400,11 @@ hipError_t launch_interp(bool full, const TapeDesc* tapes_dev, uint32_t n_tapes,
   if (full)
     hipLaunchKernelGGL(zkir_interp_kernel<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, tapes_dev, n_tapes,
                        passes_per_tape, n_vectors, inputs, outputs, (uint4*)gslot_pool, gslots_per_block,
-                       unsat_per_tape, stats);
+                       unsat_per_tape, stats, work_counter);
   else
     hipLaunchKernelGGL(zkir_interp_kernel<false>, dim3(grid), dim3(kBlock), lds_bytes, stream, tapes_dev, n_tapes,
                        passes_per_tape, n_vectors, inputs, outputs, (uint4*)gslot_pool, gslots_per_block,
-                       unsat_per_tape, stats);
+                       unsat_per_tape, stats, work_counter);
   return hipGetLastError();
 }
 

@@ -19,7 +19,7 @@ namespace zkir {
 hipError_t launch_interp(bool full, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
-                         uint32_t grid, hipStream_t stream);
+                         uint32_t* work_counter, uint32_t grid, hipStream_t stream);
 hipError_t interp_blocks_per_cu(bool full, uint32_t lslots, int* blocks);
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream);
 hipError_t launch_int_mul_rate(int which, uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
@@ -47,6 +47,7 @@ struct zkir_ctx {
   void* desc_buf = nullptr;
   size_t desc_buf_bytes = 0;
   void* result_buf = nullptr;  // 4 x uint64 for the host-pointer entry points
+  void* work_counter = nullptr;  // uint32 the workgroups of a launch draw work items from
   void* io_in = nullptr;
   size_t io_in_bytes = 0;
   void* io_out = nullptr;
@@ -138,6 +139,7 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
   if (rc) return rc;
   const uint32_t passes = (uint32_t)((N + ZKIR_BLOCK_THREADS - 1) / ZKIR_BLOCK_THREADS);
   const uint64_t work = (uint64_t)n * passes;
+  if (work >= (1ull << 32) - (1u << 20)) return fail(ctx, ZKIR_E_LIMIT, "too many (tape, pass) work items for one launch");
   const uint32_t grid = pick_grid(ctx, work, L.full, L.max_lslots);
   const size_t slot_bytes = (size_t)2 * ZKIR_BLOCK_THREADS * 16;
   rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, (size_t)grid * L.max_gslots * slot_bytes);
@@ -147,8 +149,10 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
   HIP_TRY(ctx, hipMemcpyAsync(ctx->desc_buf, L.descs.data(), (size_t)n * sizeof(TapeDesc), hipMemcpyHostToDevice, stream));
   // L.descs is pageable host memory: hipMemcpyAsync has consumed it when it returns,
   // and the device-side staging buffer is only rewritten by later work on `stream`.
+  HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, 256, stream));
   hipError_t e = zkir::launch_interp(L.full, (const TapeDesc*)ctx->desc_buf, n, passes, N, in_dev, out_dev, ctx->gslot_pool,
-                                     L.max_gslots, L.max_lslots, unsat_dev, stats_dev, grid, stream);
+                                     L.max_gslots, L.max_lslots, unsat_dev, stats_dev, (uint32_t*)ctx->work_counter,
+                                     grid, stream);
   if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
   return ZKIR_OK;
 }
@@ -170,7 +174,8 @@ int32_t zkir_ctx_create(int32_t device, zkir_ctx** out) {
   if (!ctx) return ZKIR_E_NOMEM;
   ctx->device = device;
   ctx->n_cu = prop.multiProcessorCount;
-  if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->result_buf, 4 * sizeof(uint64_t)) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->result_buf, 4 * sizeof(uint64_t)) != hipSuccess ||
+      hipMalloc(&ctx->work_counter, 256) != hipSuccess) {
     delete ctx;
     return ZKIR_E_HIP;
   }
@@ -186,7 +191,7 @@ int32_t zkir_ctx_destroy(zkir_ctx* ctx) {
     (void)hipFree(kv.second.ops);
     (void)hipFree(kv.second.consts);
   }
-  void* bufs[] = {ctx->gslot_pool, ctx->desc_buf, ctx->result_buf, ctx->io_in, ctx->io_out, ctx->io_unsat};
+  void* bufs[] = {ctx->gslot_pool, ctx->desc_buf, ctx->result_buf, ctx->work_counter, ctx->io_in, ctx->io_out, ctx->io_unsat};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete ctx;

@@ -19,7 +19,7 @@ namespace zkir {
 LowerOptions default_lower_options() {
   LowerOptions o{};
   o.fold_constants = 1;
-  o.n_lslots = 8;
+  o.n_lslots = 4;
   o.reuse_slots = 1;
   o.max_ops = 0;
   o.bnot_variant = 0;
