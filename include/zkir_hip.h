@@ -184,6 +184,11 @@ int32_t zkir_generator_config_default(zkir_generator_config* cfg);
  * point of the xorshift (src/rng.rs:18-24) and is rejected.  cfg may be NULL. */
 int32_t zkir_generate(uint64_t seed, const zkir_generator_config* cfg, zkir_circuit** out);
 
+/* The two counts generate() prints while it runs, "Generating {} instructions..." and
+ * "Generated {}/{} instructions" (src/generator.rs:148, :158): instructions asked for
+ * and top-level instructions produced.  Zero for circuits that were parsed, not generated. */
+int32_t zkir_circuit_generation_counts(const zkir_circuit* c, uint64_t* requested, uint64_t* generated);
+
 /* The first `n` values Rng::next would return for `seed` (src/rng.rs:18-24). */
 int32_t zkir_rng_stream(uint64_t seed, uint32_t n, uint64_t* out);
 

@@ -114,6 +114,7 @@ class Generator:
         instrs = []
         self.stack.append([])
         n = self.rng.rand(self.min_instructions, self.max_instructions)
+        self.requested = n  # "Generating {} instructions..." (:148)
         for _ in range(self.forced_inputs):
             instrs.append(self.gen_var_decl(("field", None), "input", None))
         for _ in range(n):
@@ -123,6 +124,7 @@ class Generator:
                 self.n_instr = 0
         self.stack.pop()
         assert not self.stack
+        self.generated = len(instrs)  # "Generated {}/{} instructions" (:158)
         return dict(vars=self.all_vars, instrs=instrs)
 
     def generate_instr(self):  # :166-208

@@ -349,3 +349,21 @@ def test_gadget_shape():
     outs, unsat, _ = F.eval_tape_one(t.ops(), t.consts(), [1, 2, 3])
     assert [outs[k] for k in range(45)] == it.outputs and unsat == []
     assert "signal output sq_0_0;" in z.CircomTranspiler(c).transpile_circuit()
+
+
+def test_cli_reproduces_reference_main(tmp_path):
+    """`cargo run` with a fixed seed (src/main.rs:81-92): progress lines, {:#?}, source, and the file."""
+    from zkir_amd import cli
+    for seed in (3, 12345):
+        g = R.Generator(R.Rng(seed))
+        ref = g.generate()
+        text, source = cli.render(seed)
+        assert source == R.transpile_circuit(ref)
+        lines = text.split("\n")
+        assert lines[0] == "Generating %d instructions..." % g.requested
+        assert lines[1] == "Generated %d/%d instructions" % (g.generated, g.requested)
+        assert lines[2] == "[" and text.endswith(source + "\n")
+        assert 15 <= g.requested <= 30 and g.generated <= g.requested
+    out = tmp_path / "circuit.circom"
+    cli.main(["--seed", "3", "--out", str(out)])
+    assert out.read_text() == cli.render(3)[1]

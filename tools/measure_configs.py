@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Measures the BASELINE.json configurations that are not the headline line:
+  config 3: many distinct generated circuits x 1024 vectors each, one launch per group
+  config 5: the deep Poseidon-style gadget x 2^16 vectors
+Run on a GPU box:  python tools/measure_configs.py [n_circuits]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+
+    import zkir_amd as z
+    from zkir_amd import campaign
+
+    n_circuits = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    n_vec = 1024
+    dev = torch.device("cuda:0")
+    ctx = z.Context(0)
+    t0 = time.time()
+    tapes = [t for _, cls, t in campaign.lower_parallel(range(n_circuits), 7, processes=16) if t is not None]
+    # longest tapes first: the work queue hands items out in order, so the tail is made of short ones
+    tapes.sort(key=lambda t: -t.hdr.n_ops)
+    host_s = time.time() - t0
+    tids = [ctx.upload(t) for t in tapes]
+    words = sum(t.hdr.n_inputs for t in tapes) * 8 * n_vec
+    inp = torch.randint(0, 1 << 32, (words,), dtype=torch.int64, device=dev).to(torch.int32)
+    off = 0
+    for t in tapes:
+        blk = inp[off:off + t.hdr.n_inputs * 8 * n_vec].view(t.hdr.n_inputs, 8, n_vec)
+        blk[:, 7, :] &= 0x0FFFFFFF
+        off += t.hdr.n_inputs * 8 * n_vec
+    unsat = torch.zeros(len(tapes), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    group = int(os.environ.get('ZKIR_GROUP', len(tids)))
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for g in range(0, len(tids), group):
+            ids = tids[g:g + group]
+            in_off = sum(t.hdr.n_inputs for t in tapes[:g]) * 8 * n_vec * 4
+            ctx.eval_multi_dev(ids, inp.data_ptr() + in_off, n_vec, unsat.data_ptr() + 8 * g, stream)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+    checks = sum(t.hdr.n_constraints for t in tapes) * n_vec
+    muls = sum(t.hdr.n_constraints + t.hdr.n_mul_ops for t in tapes) * n_vec
+    print(json.dumps({"config": "3: %d distinct circuits (%d lowered OK, %d..%d constraints) x %d vectors" % (
+        n_circuits, len(tapes), min(t.hdr.n_constraints for t in tapes), max(t.hdr.n_constraints for t in tapes), n_vec),
+        "gpu_ms": 1e3 * dt, "checks_per_s": checks / dt, "fr_mul_per_s": muls / dt, "unsat": int(unsat.sum()),
+        "host_generate_lower_s_16_procs": host_s}))
+
+
+if __name__ == "__main__":
+    main()

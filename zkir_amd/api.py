@@ -70,6 +70,7 @@ def _load():
         "zkir_generator_config_default": [P(GeneratorConfig)],
         "zkir_generate": [c_uint64, P(GeneratorConfig), P(c_void_p)],
         "zkir_rng_stream": [c_uint64, c_uint32, P(c_uint64)],
+        "zkir_circuit_generation_counts": [c_void_p, P(c_uint64), P(c_uint64)],
         "zkir_circuit_parse": [c_char_p, P(c_void_p)],
         "zkir_circuit_print": [c_void_p, c_char_p, c_size_t, P(c_size_t)],
         "zkir_circuit_transpile_circom": [c_void_p, c_char_p, c_size_t, P(c_size_t)],
@@ -164,6 +165,12 @@ class Circuit:
 
     def text(self):
         return _text(lib.zkir_circuit_print, self._h)
+
+    def generation_counts(self):
+        """(instructions asked for, top-level instructions produced): reference src/generator.rs:148,158."""
+        a, b = c_uint64(), c_uint64()
+        _host_check(lib.zkir_circuit_generation_counts(self._h, byref(a), byref(b)))
+        return a.value, b.value
 
     def debug(self):
         """`{:#?}` of circuit.instructions (what reference src/main.rs:91 prints)."""

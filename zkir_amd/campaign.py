@@ -39,6 +39,28 @@ def campaign_config(circuit_id, min_constraints=64, max_constraints=4096):
     return g
 
 
+def _lower_one(args):
+    cid, base_seed = args
+    try:
+        tape = api.Lowerer(api.Generator(circuit_seed(base_seed, cid), campaign_config(cid)).generate()).lower()
+        return cid, 0, bytes(tape.hdr), tape.blob()
+    except api.LowerRejected as e:
+        return cid, e.status_class, None, None
+
+
+def lower_parallel(circuit_ids, base_seed, processes=8):
+    """Generate and lower campaign circuits on `processes` host cores (the generator keeps the
+    reference's linear scans over the scope, so large circuits cost host time); yields
+    (circuit id, class, Tape or None) in id order."""
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(processes) as pool:
+        for cid, cls, hdr, blob in pool.imap(_lower_one, [(c, base_seed) for c in circuit_ids], chunksize=4):
+            if hdr is None:
+                yield cid, cls, None
+            else:
+                yield cid, cls, api.Tape.from_parts(api.TapeHdr.from_buffer_copy(hdr), blob)
+
+
 class LocalResult:
     """What one rank found: counters plus the ids it flags."""
 

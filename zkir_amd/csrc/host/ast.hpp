@@ -165,4 +165,5 @@ struct Circuit {
 // opaque handle of the C ABI
 struct zkir_circuit {
   zkir::Circuit circuit;
+  size_t requested = 0, generated = 0;  // what Generator::generate reported, if it made this circuit
 };

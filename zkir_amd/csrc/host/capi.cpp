@@ -72,9 +72,18 @@ int32_t zkir_generate(uint64_t seed, const zkir_generator_config* cfg, zkir_circ
     zkir::Generator g(zkir::Rng::from_seed(seed), c);
     auto* h = new zkir_circuit();
     h->circuit = g.generate();
+    h->requested = g.requested();
+    h->generated = g.generated();
     *out = h;
     return ZKIR_OK;
   });
+}
+
+int32_t zkir_circuit_generation_counts(const zkir_circuit* c, uint64_t* requested, uint64_t* generated) {
+  if (!c || !requested || !generated) return ZKIR_E_INVALID;
+  *requested = c->requested;
+  *generated = c->generated;
+  return ZKIR_OK;
 }
 
 int32_t zkir_rng_stream(uint64_t seed, uint32_t n, uint64_t* out_vals) {

@@ -1,6 +1,6 @@
-// See fr_host.hpp.  Plain multi-word arithmetic: schoolbook products into 512 bits
-// and bitwise long division for every reduction; clarity over speed, the lowerer
-// folds at most a few thousand constants per circuit.
+// See fr_host.hpp.  Plain multi-word arithmetic on 64-bit words: products go through a
+// word-serial Montgomery reduction (constants are parsed and folded by the thousand when a
+// large circuit is lowered); the rare integer operators use bitwise long division.
 #include "fr_host.hpp"
 
 #include <algorithm>
@@ -113,13 +113,21 @@ const U256& half() {
 
 bool parse_decimal(const std::string& s, U256* out) {
   if (s.empty()) return false;
+  // 18 digits at a time: acc = acc * 10^k + chunk (mod p)
   U256 acc;
-  const U256 ten = U256::from_u64(10);
-  for (char ch : s) {
-    if (ch < '0' || ch > '9') return false;
-    acc = add(mul(acc, ten), U256::from_u64((uint64_t)(ch - '0')));
+  size_t i = 0;
+  while (i < s.size()) {
+    uint64_t chunk = 0, scale = 1;
+    size_t k = 0;
+    for (; k < 18 && i < s.size(); k++, i++) {
+      const char ch = s[i];
+      if (ch < '0' || ch > '9') return false;
+      chunk = chunk * 10 + (uint64_t)(ch - '0');
+      scale *= 10;
+    }
+    acc = acc.is_zero() ? U256::from_u64(chunk) : add(mul(acc, U256::from_u64(scale)), U256::from_u64(chunk));
   }
-  *out = acc;
+  *out = acc;  // every step kept it below p
   return true;
 }
 
@@ -150,10 +158,48 @@ U256 sub(const U256& a, const U256& b) {
   return e;
 }
 U256 neg(const U256& a) { return a.is_zero() ? a : sub(U256(), a); }
-U256 mul(const U256& a, const U256& b) {
-  U256 r;
-  divmod_wide(mul_wide(a, b), modulus(), nullptr, &r);
+namespace {
+// t * 2^-256 mod p for a 512-bit t < p * 2^256
+U256 mont_reduce(U512 t) {
+  static const uint64_t np = 0xc2e1f593efffffffull;  // -p^-1 mod 2^64
+  const U256& p = modulus();
+  uint64_t top = 0;
+  for (int i = 0; i < 4; i++) {
+    const uint64_t m = t.w[i] * np;
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)m * p.w[j] + t.w[i + j];
+      t.w[i + j] = (uint64_t)c;
+      c >>= 64;
+    }
+    for (int k = i + 4; k < 8 && c; k++) {
+      c += t.w[k];
+      t.w[k] = (uint64_t)c;
+      c >>= 64;
+    }
+    top += (uint64_t)c;
+  }
+  U256 r, d;
+  for (int i = 0; i < 4; i++) r.w[i] = t.w[i + 4];
+  if (top || !sub_raw(d, r, p)) {
+    sub_raw(d, r, p);
+    return d;
+  }
   return r;
+}
+const U256& r2() {  // 2^512 mod p
+  static const U256 v = [] {
+    U256 x;
+    x.w = {0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull, 0x0216d0b17f4e44a5ull};
+    return x;
+  }();
+  return v;
+}
+}  // namespace
+
+U256 mul(const U256& a, const U256& b) {
+  // (a*b*R^-1) * R^2 * R^-1 = a*b mod p
+  return mont_reduce(mul_wide(mont_reduce(mul_wide(a, b)), r2()));
 }
 U256 pow(const U256& a, const U256& e) {
   U256 acc = U256::from_u64(1);
