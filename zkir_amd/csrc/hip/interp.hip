@@ -67,20 +67,37 @@ struct LaneCtx {
 
 __device__ __forceinline__ Fr load_operand(uint32_t o, const Fr& acc, const LaneCtx& cx) {
   const uint32_t kind = o >> ZKIR_KIND_SHIFT, idx = o & ZKIR_INDEX_MASK;
-  if (kind == ZKIR_KIND_ACC) return acc;
-  if (kind == ZKIR_KIND_LSLOT) return load_lds_slot(idx);
-  if (kind == ZKIR_KIND_CONST) {
-    uniform_u32_t c = cx.consts + (size_t)idx * 8;
-    return Fr{{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]}};
+  Fr r;
+  switch (kind) {
+    case ZKIR_KIND_ACC:
+      r = acc;
+      break;
+    case ZKIR_KIND_LSLOT:
+      r = load_lds_slot(idx);
+      break;
+    case ZKIR_KIND_CONST: {
+      uniform_u32_t c = cx.consts + (size_t)idx * 8;
+      r = Fr{{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]}};
+      break;
+    }
+    default:
+      r = load_slot(cx.gslots, idx);
+      break;
   }
-  return load_slot(cx.gslots, idx);
+  return r;
 }
 __device__ __forceinline__ void store_operand(uint32_t o, const Fr& v, const LaneCtx& cx) {
   const uint32_t kind = o >> ZKIR_KIND_SHIFT, idx = o & ZKIR_INDEX_MASK;
-  if (kind == ZKIR_KIND_LSLOT)
-    store_lds_slot(idx, v);
-  else if (kind == ZKIR_KIND_GSLOT)
-    store_slot(cx.gslots, idx, v);
+  switch (kind) {
+    case ZKIR_KIND_LSLOT:
+      store_lds_slot(idx, v);
+      break;
+    case ZKIR_KIND_GSLOT:
+      store_slot(cx.gslots, idx, v);
+      break;
+    default:
+      break;
+  }
 }
 
 // ---- the operators that are not + - * -----------------------------------

@@ -22,6 +22,48 @@ GeneratorConfig default_generator_config() {
 }
 
 // ---- ScopeStack (generator.rs:48-115) ----
+void Generator::OrderedSet::resize(size_t n) {
+  if (n < flag_.size()) {
+    for (size_t p = n; p < flag_.size(); p++) set(p, false);
+    flag_.resize(n);
+    return;
+  }
+  flag_.resize(n, 0);
+  if (n + 1 > tree_.size()) {  // grow to the next power of two and rebuild
+    size_t cap = 16;
+    while (cap < n + 1) cap *= 2;
+    tree_.assign(cap, 0);
+    for (size_t p = 0; p < flag_.size(); p++)
+      if (flag_[p])
+        for (size_t i = p + 1; i < tree_.size(); i += i & (~i + 1)) tree_[i] += 1;
+  }
+}
+void Generator::OrderedSet::set(size_t pos, bool on) {
+  if (pos >= flag_.size() || (bool)flag_[pos] == on) return;
+  flag_[pos] = on;
+  count_ += on ? 1 : (size_t)-1;
+  for (size_t i = pos + 1; i < tree_.size(); i += i & (~i + 1)) tree_[i] += on ? 1 : -1;
+}
+size_t Generator::OrderedSet::select(size_t k) const {
+  size_t pos = 0;
+  int64_t rem = (int64_t)k + 1;
+  for (size_t step = tree_.size() / 2; step > 0; step /= 2)
+    if (pos + step < tree_.size() && tree_[pos + step] < rem) {
+      pos += step;
+      rem -= tree_[pos];
+    }
+  return pos;  // 0-based position
+}
+
+void Generator::ScopeStack::refresh(size_t pos) {
+  const Variable& v = flat[pos];
+  const bool field = !v.var_type.is_array;
+  ready_fields.set(pos, field && v.all_initialized());
+  open_outputs.set(pos, v.role.is_output() && field && !v.all_initialized());
+  touched_arrays.set(pos, !field && v.any_initialized());
+  ready_signals.set(pos, v.role.is_signal && field && v.all_initialized());
+}
+
 Variable Generator::ScopeStack::add_var(std::string name, VariableType t, VariableRole r,
                                         std::vector<bool> initialized) {
   Variable var;
@@ -30,29 +72,47 @@ Variable Generator::ScopeStack::add_var(std::string name, VariableType t, Variab
   var.var_type = t;
   var.role = r;
   var.initialized = std::move(initialized);
-  stack.back().vars.push_back(var);
+  const size_t pos = flat.size();
+  flat.push_back(var);
   all_vars.push_back(var);  // a copy taken now: later mark_initialized calls do not reach it (generator.rs:84)
   next_id += 1;
+  if (r.is_local()) {
+    n_local++;
+    (t.is_array ? local_arrays : local_fields).push_back(pos);
+  }
+  if (r.is_output()) n_output++;
+  for (OrderedSet* s : {&ready_fields, &open_outputs, &touched_arrays, &ready_signals}) s->resize(pos + 1);
+  refresh(pos);
   return var;
 }
 
-std::vector<const Variable*> Generator::ScopeStack::get_scope_vars() const {
-  std::vector<const Variable*> r;
-  for (const Scope& s : stack)
-    for (const Variable& v : s.vars) r.push_back(&v);
-  return r;
+void Generator::ScopeStack::leave_scope() {
+  const size_t begin = scope_begin.back();
+  scope_begin.pop_back();
+  for (size_t p = begin; p < flat.size(); p++) {
+    if (flat[p].role.is_local()) n_local--;
+    if (flat[p].role.is_output()) n_output--;
+  }
+  while (!local_fields.empty() && local_fields.back() >= begin) local_fields.pop_back();
+  while (!local_arrays.empty() && local_arrays.back() >= begin) local_arrays.pop_back();
+  for (OrderedSet* s : {&ready_fields, &open_outputs, &touched_arrays, &ready_signals}) s->resize(begin);
+  flat.resize(begin);
 }
 
 void Generator::ScopeStack::mark_initialized(const VarRef& var_id) {
-  for (Scope& scope : stack)
-    for (Variable& var : scope.vars)
-      if (var.var_ref.id == var_id.id) {
-        if (var_id.idx)
-          var.initialized.at(*var_id.idx) = true;
-        else
-          var.initialized = std::vector<bool>{true};
-        return;
-      }
+  // ids grow with the position in `flat`: binary search
+  size_t lo = 0, hi = flat.size();
+  while (lo < hi) {
+    const size_t mid = (lo + hi) / 2;
+    if (flat[mid].var_ref.id < var_id.id) lo = mid + 1; else hi = mid;
+  }
+  if (lo == flat.size() || flat[lo].var_ref.id != var_id.id) return;  // not in scope: nothing to mark (generator.rs:101-114)
+  Variable& var = flat[lo];
+  if (var_id.idx)
+    var.initialized.at(*var_id.idx) = true;
+  else
+    var.initialized = std::vector<bool>{true};
+  refresh(lo);
 }
 
 // ---- Generator ----
@@ -86,7 +146,7 @@ Circuit Generator::generate() {
   generated_ = instructions.size();
 
   scope_stack_.leave_scope();
-  if (!scope_stack_.stack.empty()) throw std::logic_error("scope stack not empty");  // generator.rs:161
+  if (!scope_stack_.empty()) throw std::logic_error("scope stack not empty");  // generator.rs:161
   return Circuit(scope_stack_.all_vars, std::move(instructions));
 }
 
@@ -94,9 +154,9 @@ std::optional<Instruction> Generator::generate_instr() {
   if (n_instr_ >= cfg_.statement_budget) return std::nullopt;
   n_instr_ += 1;
 
-  const bool has_vars = has_vars_of_type([](const Variable& v) { return v.role.is_local(); });
-  const bool has_arrays = has_vars_of_type([](const Variable& v) { return v.role.is_local() && v.var_type.is_array; });
-  const bool has_output_signals = has_vars_of_type([](const Variable& v) { return v.role.is_output(); });
+  const bool has_vars = scope_stack_.n_local > 0;                // any Local in scope (generator.rs:174-177)
+  const bool has_arrays = !scope_stack_.local_arrays.empty();    // any Local array (:178-182)
+  const bool has_output_signals = scope_stack_.n_output > 0;     // any Output signal (:183-186)
 
   // candidate order of generator.rs:188-204
   enum Cand { kVarDecl, kFor, kAssign, kArrayAssign, kConstraint };
@@ -166,13 +226,11 @@ std::optional<Instruction> Generator::gen_var_decl(std::optional<VariableType> t
 }
 
 std::optional<Instruction> Generator::gen_assign() {
-  std::vector<VarRef> vars;
-  for (const Variable* v : scope_stack_.get_scope_vars())
-    if (v->role.is_local() && !v->var_type.is_array) vars.push_back(v->var_ref);
-
-  const VarRef* pick = rng_.rand_vec(vars);
+  // rand_vec over the Local Field variables in scope order (generator.rs:270-281)
+  const std::vector<size_t>& vars = scope_stack_.local_fields;
+  const size_t* pick = rng_.rand_vec(vars);
   if (!pick) return std::nullopt;
-  VarRef var_id = *pick;
+  VarRef var_id = scope_stack_.flat[*pick].var_ref;
   std::optional<Expr> expr = generate_expr(0);
   if (!expr) return std::nullopt;
 
@@ -181,13 +239,10 @@ std::optional<Instruction> Generator::gen_assign() {
 }
 
 std::optional<Instruction> Generator::gen_array_assign() {
-  std::vector<std::pair<VarRef, size_t>> vars;
-  for (const Variable* v : scope_stack_.get_scope_vars())
-    if (v->role.is_local() && v->var_type.is_array) vars.emplace_back(v->var_ref, v->var_type.len);
-
-  if (const auto* pick = rng_.rand_vec(vars)) {
-    const VarRef var_ref = pick->first;
-    const size_t n = pick->second;
+  // rand_vec over the Local arrays in scope order (generator.rs:292-306)
+  if (const size_t* pick = rng_.rand_vec(scope_stack_.local_arrays)) {
+    const VarRef var_ref = scope_stack_.flat[*pick].var_ref;
+    const size_t n = scope_stack_.flat[*pick].var_type.len;
     std::optional<Expr> expr = generate_expr(0);
     if (expr) {
       const size_t idx = rng_.rand(0, n - 1);
@@ -202,12 +257,10 @@ std::optional<Instruction> Generator::gen_array_assign() {
 }
 
 std::optional<Instruction> Generator::gen_constraint() {
-  std::vector<VarRef> vars;
-  for (const Variable* v : scope_stack_.get_scope_vars())
-    if (v->role.is_output() && !v->var_type.is_array && !v->all_initialized()) vars.push_back(v->var_ref);
-
-  if (const VarRef* pick = rng_.rand_vec(vars)) {
-    const VarRef var_id = *pick;
+  // rand_vec over the Output Field signals not yet initialised, in scope order (generator.rs:330-343)
+  const size_t n_open = scope_stack_.open_outputs.count();
+  if (n_open) {
+    const VarRef var_id = scope_stack_.flat[scope_stack_.open_outputs.select(rng_.rand(0, n_open - 1))].var_ref;
     // marked before the right-hand side is generated (generator.rs:344-346): `out <== out` is reachable
     scope_stack_.mark_initialized(var_id);
     std::optional<Expr> expr = generate_expr(0);
@@ -289,10 +342,8 @@ std::optional<Expr> Generator::generate_expr(size_t depth) {
   // 1/3 chance of stopping early; unreachable at the reference's limit of 1 (generator.rs:490-493)
   if (depth >= 1 && rng_.rand(1, 3) == 1) return Expr::Constant(std::to_string(rng_.next()));
 
-  const bool has_field_vars =
-      has_vars_of_type([](const Variable& v) { return !v.var_type.is_array && v.all_initialized(); });
-  const bool has_array_vars =
-      has_vars_of_type([](const Variable& v) { return v.var_type.is_array && v.any_initialized(); });
+  const bool has_field_vars = scope_stack_.ready_fields.count() > 0;    // generator.rs:496-499
+  const bool has_array_vars = scope_stack_.touched_arrays.count() > 0;  // generator.rs:502-505
 
   // the fixed entries of generator.rs:507-531, in order; -1 stands for gen_constant
   static const int kAll[] = {
@@ -319,20 +370,17 @@ std::optional<Expr> Generator::generate_expr(size_t depth) {
 }
 
 std::optional<Expr> Generator::gen_var_ref(size_t) {
-  std::vector<VarRef> vars;
-  for (const Variable* v : scope_stack_.get_scope_vars())
-    if (v->all_initialized() && !v->var_type.is_array) vars.push_back(v->var_ref);
-  const VarRef* pick = rng_.rand_vec(vars);
-  if (!pick) return std::nullopt;
-  return Expr::Var(*pick);
+  const size_t n = scope_stack_.ready_fields.count();
+  if (!n) return std::nullopt;
+  return Expr::Var(scope_stack_.flat[scope_stack_.ready_fields.select(rng_.rand(0, n - 1))].var_ref);
 }
 
 std::optional<Expr> Generator::gen_constant(size_t) { return Expr::Constant(std::to_string(rng_.next())); }
 
 std::optional<Expr> Generator::gen_array_index(size_t) {
   std::vector<std::pair<VarRef, size_t>> vars;
-  for (const Variable* v : scope_stack_.get_scope_vars()) {
-    if (!v->var_type.is_array || !v->any_initialized()) continue;
+  for (size_t k = 0, n = scope_stack_.touched_arrays.count(); k < n; k++) {
+    const Variable* v = &scope_stack_.flat[scope_stack_.touched_arrays.select(k)];
     const std::vector<size_t> indices = v->get_initialized();
     // a position in 0..=len, not one of `indices` (generator.rs:584): it can name an
     // unwritten element, or one past the end when every element is written
@@ -353,11 +401,10 @@ std::optional<Expr> Generator::gen_array_index(size_t) {
 
 // a*x + b style term over readable signals and constants: degree <= 1 in the signals
 Expr Generator::gen_linear() {
-  std::vector<VarRef> sigs;
-  for (const Variable* v : scope_stack_.get_scope_vars())
-    if (v->role.is_signal && !v->var_type.is_array && v->all_initialized()) sigs.push_back(v->var_ref);
+  const OrderedSet& sigs = scope_stack_.ready_signals;
   auto term = [&]() -> Expr {
-    if (!sigs.empty() && rng_.rand(0, 3) != 0) return Expr::Var(*rng_.rand_vec(sigs));
+    if (sigs.count() && rng_.rand(0, 3) != 0)
+      return Expr::Var(scope_stack_.flat[sigs.select(rng_.rand(0, sigs.count() - 1))].var_ref);
     return Expr::Constant(std::to_string(rng_.next()));
   };
   Expr t = term();

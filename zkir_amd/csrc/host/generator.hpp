@@ -2,6 +2,7 @@
 // into a GeneratorConfig whose defaults are those literals, so the default
 // configuration consumes the random stream draw for draw like the Rust code.
 #pragma once
+#include <cstdint>
 #include <optional>
 #include <vector>
 
@@ -42,27 +43,46 @@ class Generator {
   std::optional<Expr> gen_array_index(size_t depth);  // :572-601
 
  private:
-  // generator.rs:30-115
-  struct Scope {
-    std::vector<Variable> vars;
+  // generator.rs:30-115.  The reference answers every "which variables can I use here"
+  // question by collecting and scanning all variables in scope; that is quadratic in the
+  // circuit size.  The same answers, in the same scope order, are kept here incrementally:
+  // plain position lists for the static categories, and order-statistic (Fenwick) sets for
+  // the ones that change when a variable becomes initialised.
+  class OrderedSet {
+   public:
+    void resize(size_t n);          // positions 0..n-1 exist; new ones are absent
+    void set(size_t pos, bool on);
+    bool test(size_t pos) const { return pos < flag_.size() && flag_[pos]; }
+    size_t count() const { return count_; }
+    size_t select(size_t k) const;  // position of the k-th (0-based) member
+   private:
+    std::vector<uint8_t> flag_;
+    std::vector<int32_t> tree_;     // Fenwick tree over flag_, 1-based, capacity a power of two
+    size_t count_ = 0;
   };
   struct ScopeStack {
-    std::vector<Scope> stack;
+    std::vector<Variable> flat;        // every variable in scope, outermost scope first
+    std::vector<size_t> scope_begin;   // first position of each open scope
     std::vector<Variable> all_vars;
     size_t next_id = 0;
-    void enter_scope() { stack.emplace_back(); }
-    void leave_scope() { stack.pop_back(); }
+    // static categories (positions into `flat`, ascending)
+    std::vector<size_t> local_fields, local_arrays;
+    size_t n_local = 0, n_output = 0;
+    // dynamic categories
+    OrderedSet ready_fields;     // Field and all_initialized           (gen_var_ref)
+    OrderedSet open_outputs;     // Output Field not yet initialised    (gen_constraint)
+    OrderedSet touched_arrays;   // Array with any element initialised  (gen_array_index)
+    OrderedSet ready_signals;    // signal, Field, all_initialized      (extension: gen_linear)
+
+    void enter_scope() { scope_begin.push_back(flat.size()); }
+    void leave_scope();
+    bool empty() const { return scope_begin.empty(); }
     Variable add_var(std::string name, VariableType t, VariableRole r, std::vector<bool> initialized);
-    std::vector<const Variable*> get_scope_vars() const;
     void mark_initialized(const VarRef& v);
+   private:
+    void refresh(size_t pos);
   };
 
-  template <class F>
-  bool has_vars_of_type(F pred) const {
-    for (const Variable* v : scope_stack_.get_scope_vars())
-      if (pred(*v)) return true;
-    return false;
-  }
   std::optional<Instruction> gen_var_decl_default() { return gen_var_decl(std::nullopt, std::nullopt, std::nullopt); }
   std::optional<Expr> gen_bin_expr(ExprKind k, size_t depth);
   std::optional<Expr> gen_un_expr(ExprKind k, size_t depth);
