@@ -27,8 +27,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, datasheet
 MULHI_PEAK_THEORETICAL = 256 * 4 * 16 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock: one v_mul_hi_u32 per lane per clock
 
 
-def workload_tape(z):
+def workload_tape(z, signal_window=0):
     g = z.default_generator_config()
+    g.signal_window = signal_window
     g.min_instructions = g.max_instructions = 4200
     g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = 16, 1, 1, 1
     g.no_loops, g.safe_array_index = 1, 1
@@ -80,6 +81,9 @@ def main():
                     help="config2 (default, the headline line) or gadget (the deep Poseidon-style chain, "
                          "2^16 vectors, outputs not requested)")
     ap.add_argument("--gadget-rounds", type=int, default=20834)
+    ap.add_argument("--signal-window", type=int, default=0,
+                    help="config2 only: linear terms read the inputs and the last W signals instead of any "
+                         "earlier signal (0 = any, the default line)")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,7 +103,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     gadget = args.workload == "gadget"
-    tape = gadget_tape(z, args.gadget_rounds) if gadget else workload_tape(z)
+    tape = gadget_tape(z, args.gadget_rounds) if gadget else workload_tape(z, args.signal_window)
     h = tape.hdr
     if gadget and args.log2_vectors == LOG2_VECTORS:
         args.log2_vectors = 16
@@ -174,8 +178,9 @@ def main():
             "config": {
                 "workload": ("Poseidon-style gadget chain (width 4, %d rounds) x 2^%d vectors per GPU; witness + checks, "
                              "outputs not requested" % (args.gadget_rounds, args.log2_vectors)) if gadget else
-                            ("one generated circuit (extended generator, seed %d) x 2^%d uniform input vectors per GPU; "
-                             "witness + outputs + checks" % (WORKLOAD_SEED, args.log2_vectors)),
+                            ("one generated circuit (extended generator, seed %d%s) x 2^%d uniform input vectors per GPU; "
+                             "witness + outputs + checks" % (WORKLOAD_SEED, ", signal window %d" % args.signal_window
+                                                             if args.signal_window else "", args.log2_vectors)),
                 "n_constraints": h.n_constraints, "n_mul_ops": h.n_mul_ops, "n_ops": h.n_ops,
                 "n_inputs": h.n_inputs, "n_outputs": h.n_outputs, "vectors_per_gpu": n,
                 "device_slots": h.n_gslots, "window_slots": h.n_lslots,

@@ -174,7 +174,10 @@ typedef struct zkir_generator_config {
                                   reference draws a position in 0..=len,
                                   src/generator.rs:584, which can be unwritten
                                   or one past the end)                        */
-  uint32_t reserved[5];
+  uint32_t signal_window;      /* quadratic_aware: linear terms draw among the inputs
+                                  and the last `signal_window` readable signals
+                                  instead of all of them (0 = all)            */
+  uint32_t reserved[4];
 } zkir_generator_config;
 
 int32_t zkir_generator_config_default(zkir_generator_config* cfg);

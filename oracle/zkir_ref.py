@@ -76,7 +76,7 @@ class Generator:
         self.loop_init_max, self.loop_bound_max, self.loop_body_max = 30, 60, 5  # :406 :416 :436
         self.name_len = 8  # :264
         self.inputs_readable = self.arithmetic_only = self.quadratic_aware = self.no_loops = 0
-        self.forced_inputs = self.safe_array_index = 0
+        self.forced_inputs = self.safe_array_index = self.signal_window = 0
         for k, v in cfg.items():
             assert hasattr(self, k), k
             setattr(self, k, v)
@@ -276,7 +276,11 @@ class Generator:
 
         def term():
             if sigs and self.rng.rand(0, 3) != 0:
-                return ("var", self.rng.rand_vec(sigs), None)
+                k = self.rng.rand(0, len(sigs) - 1)
+                keep = self.forced_inputs + self.signal_window
+                if self.signal_window and len(sigs) > keep and self.forced_inputs <= k < len(sigs) - self.signal_window:
+                    k = k % keep if k % keep < self.forced_inputs else len(sigs) - keep + k % keep
+                return ("var", sigs[k], None)
             return ("const", str(self.rng.next()))
 
         t = term()

@@ -79,6 +79,11 @@ def test_generator_and_transpiler_against_fixture():
 def test_generator_matches_restatement_over_seeds():
     for seed in list(range(1, 120)) + [2**63, 2**64 - 1]:
         assert z.Generator(seed).generate().text() == R.print_text(R.Generator(R.Rng(seed)).generate())
+    cfg = dict(min_instructions=200, max_instructions=200, forced_inputs=5, inputs_readable=1, arithmetic_only=1,
+               quadratic_aware=1, no_loops=1, safe_array_index=1, signal_window=6)
+    for seed in range(1, 12):
+        assert z.Generator(seed, ext_config(**cfg)).generate().text() == \
+            R.print_text(R.Generator(R.Rng(seed), **cfg).generate())
     cfg = dict(min_instructions=40, max_instructions=80, max_expr_depth=3, inputs_readable=1, safe_array_index=1)
     for seed in range(1, 40):
         assert z.Generator(seed, ext_config(**cfg)).generate().text() == \

@@ -403,8 +403,15 @@ std::optional<Expr> Generator::gen_array_index(size_t) {
 Expr Generator::gen_linear() {
   const OrderedSet& sigs = scope_stack_.ready_signals;
   auto term = [&]() -> Expr {
-    if (sigs.count() && rng_.rand(0, 3) != 0)
-      return Expr::Var(scope_stack_.flat[sigs.select(rng_.rand(0, sigs.count() - 1))].var_ref);
+    if (sigs.count() && rng_.rand(0, 3) != 0) {
+      size_t k = rng_.rand(0, sigs.count() - 1);
+      // extension: with a signal window, a draw that falls on an older signal is folded onto
+      // the forced inputs and the most recent `signal_window` signals
+      const size_t keep = (size_t)cfg_.forced_inputs + cfg_.signal_window;
+      if (cfg_.signal_window && sigs.count() > keep && k >= cfg_.forced_inputs && k < sigs.count() - cfg_.signal_window)
+        k = (k % keep < cfg_.forced_inputs) ? k % keep : sigs.count() - keep + k % keep;
+      return Expr::Var(scope_stack_.flat[sigs.select(k)].var_ref);
+    }
     return Expr::Constant(std::to_string(rng_.next()));
   };
   Expr t = term();
