@@ -1,0 +1,235 @@
+"""The generated interpreter stream (tools/gen_interp_asm.py), executed instruction by
+instruction on the model in isa_model.py for single lanes, against the big-integer tape
+interpreter of the oracle.  Covers the arithmetic, the register plan, the waits and, above
+all, that every memory access stays inside its buffer."""
+import importlib.util
+import os
+import random
+
+import pytest
+
+from oracle import fr_ref as F
+from tests import isa_model as IM
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("gen_interp_asm", os.path.join(ROOT, "tools", "gen_interp_asm.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+G = _gen()
+PROG, LABELS = IM.parse_program(G.build())
+R = (1 << 256) % F.P
+
+OPS_BASE, CST_BASE, GS_BASE = 0x7F0000001000, 0x7F0010000000, 0x7F1000000000
+IN_BASE, OUT_BASE, LDS_BASE = 0x7E0000000400, 0x7D0000000800, 16
+
+
+def run_lane(ops, consts, inputs, n_outputs, n_lslots, n_gslots, vec, wave=0, lane=0, live=True, want_outputs=True,
+             block=3):
+    """inputs: list over vectors of lists of ints.  Returns (outputs list or None, unsat, first, Lane)."""
+    n_vec = len(inputs)
+    n_inputs = len(inputs[0]) if inputs else 0
+    mem = IM.Memory()
+    words = []
+    for code, dst, a, b in ops:
+        words += [code, dst, a, b]
+    mem.map("ops", OPS_BASE, max(16, 16 * len(ops)), words=words)
+    cw = []
+    for c in consts:
+        cw += F.limbs32(c * R % F.P)
+    mem.map("consts", CST_BASE, max(32, 32 * len(consts)), words=cw)
+    gs_bytes = n_gslots * 8192
+    gs = GS_BASE + block * gs_bytes
+    mem.map("gslots", gs, max(gs_bytes, 16), writable=True)
+    iw = [0] * (n_inputs * 8 * n_vec)
+    for t, vecvals in enumerate(inputs):
+        for s, x in enumerate(vecvals):
+            for l, w in enumerate(F.limbs32(x)):
+                iw[(s * 8 + l) * n_vec + t] = w
+    mem.map("inputs", IN_BASE, max(16, 4 * len(iw)), words=iw)
+    out_region = mem.map("outputs", OUT_BASE, max(16, 32 * n_outputs * n_vec), writable=True)
+    v = vec if live else 0
+    bit = 1 << lane
+    operands = {
+        "%[ops]": OPS_BASE, "%[n_ops]": len(ops), "%[consts]": CST_BASE, "%[n_consts]": len(consts),
+        "%[gslots]": gs, "%[gslot_bytes]": gs_bytes, "%[lds_base]": LDS_BASE,
+        "%[in_base]": IN_BASE, "%[out_base]": OUT_BASE if want_outputs else 0,
+        "%[n4]": 4 * n_vec, "%[live]": (0x8000000000000001 | bit) if live else (0x8000000000000001 & ~bit),
+        "%[v_lo]": wave * 2048 + lane * 16, "%[v_vec4]": 4 * v,
+    }
+    ln = IM.Lane(mem, LDS_BASE + n_lslots * 8192, lane, operands, set(range(G.VB, G.V_LAST + 1)),
+                 set(range(G.SB, G.S_LAST + 1)), result_operands=("%[unsat]", "%[first]"))
+    ln.run(PROG, LABELS)
+    outs = None
+    if want_outputs and live:
+        outs = []
+        for s in range(n_outputs):
+            limbs = [out_region.words.get(OUT_BASE + 4 * ((s * 8 + l) * n_vec + v)) for l in range(8)]
+            outs.append(None if None in limbs else F.from_limbs32(limbs))
+    elif not live:
+        assert not out_region.words, "an idle lane stored outputs"
+    return outs, ln.operand_written["%[unsat]"], ln.operand_written["%[first]"], ln
+
+
+def oracle(ops, consts, vecvals, n_outputs):
+    outs, unsat, faults = F.eval_tape_one(ops, consts, vecvals)
+    assert faults == 0
+    return [outs.get(s) for s in range(n_outputs)], unsat
+
+
+def check_tape(ops, consts, inputs, n_outputs, n_lslots, n_gslots, picks):
+    for vec, wave, lane, live in picks:
+        want_out, want_unsat = oracle(ops, consts, inputs[vec if live else 0], n_outputs)
+        got_out, unsat, first, _ = run_lane(ops, consts, inputs, n_outputs, n_lslots, n_gslots, vec, wave, lane, live)
+        if live:
+            assert got_out == want_out
+            assert unsat == len(want_unsat)
+            assert first == (want_unsat[0] if want_unsat else 0xFFFFFFFF)
+        else:
+            assert unsat == 0 and first == 0xFFFFFFFF
+
+
+def O(kind, idx=0):
+    return F.operand(kind, idx)
+
+
+def test_every_operand_kind_and_op():
+    rnd = random.Random(11)
+    consts = [0, 1, F.P - 1, rnd.randrange(F.P), (1 << 253) + 12345]
+    NONE, ACC = O(F.K_NONE), O(F.K_ACC)
+    ops = [
+        (F.OP_INPUT, O(F.K_LSLOT, 0), O(F.K_INPUT, 0), NONE),
+        (F.OP_INPUT, O(F.K_GSLOT, 0), O(F.K_INPUT, 1), NONE),
+        (F.OP_INPUT, NONE, O(F.K_INPUT, 2), NONE),
+        (F.OP_MUL, O(F.K_LSLOT, 1), ACC, O(F.K_LSLOT, 0)),             # acc * lds
+        (F.OP_MUL, O(F.K_GSLOT, 1), O(F.K_GSLOT, 0), O(F.K_CONST, 3)),  # device * const
+        (F.OP_ADD, O(F.K_GSLOT, 2), ACC, ACC),                          # acc + acc
+        (F.OP_ADD, NONE, O(F.K_LSLOT, 1), O(F.K_GSLOT, 1)),
+        (F.OP_SUB, O(F.K_LSLOT, 2), ACC, O(F.K_CONST, 2)),              # acc - (p-1)
+        (F.OP_SUB, NONE, O(F.K_CONST, 0), ACC),                         # 0 - acc
+        (F.OP_SUB, O(F.K_LSLOT, 3), O(F.K_GSLOT, 2), O(F.K_LSLOT, 2)),
+        (F.OP_NEG, O(F.K_GSLOT, 3), ACC, NONE),
+        (F.OP_NEG, NONE, O(F.K_CONST, 0), NONE),                        # -0
+        (F.OP_COPY, O(F.K_LSLOT, 0), O(F.K_GSLOT, 3), NONE),
+        (F.OP_COPY, O(F.K_GSLOT, 0), ACC, NONE),
+        (F.OP_COPY, NONE, O(F.K_CONST, 4), NONE),
+        (F.OP_MUL, NONE, ACC, ACC),                                     # square of a constant
+        (F.OP_OUTPUT, 0, ACC, NONE),
+        (F.OP_OUTPUT, 2, O(F.K_LSLOT, 3), NONE),
+        (F.OP_OUTPUT, 1, O(F.K_GSLOT, 1), NONE),
+        (F.OP_OUTPUT, 3, O(F.K_CONST, 3), NONE),
+        (F.OP_NOP, 0, 0, 0),
+        (F.OP_MUL, O(F.K_LSLOT, 1), O(F.K_LSLOT, 0), O(F.K_GSLOT, 0)),
+        (F.OP_CHECK, ACC, O(F.K_LSLOT, 0), O(F.K_GSLOT, 0)),            # holds
+        (F.OP_CHECK, O(F.K_LSLOT, 1), ACC, O(F.K_CONST, 1)),            # acc*1 == lds1: holds
+        (F.OP_CHECK, O(F.K_CONST, 3), O(F.K_LSLOT, 0), O(F.K_LSLOT, 0)),  # fails (almost surely)
+        (F.OP_CHECK, O(F.K_GSLOT, 1), O(F.K_GSLOT, 0), O(F.K_CONST, 3)),
+        (F.OP_CHECK, O(F.K_CONST, 0), O(F.K_CONST, 0), ACC),            # 0*acc == 0: holds
+    ]
+    inputs = [[rnd.randrange(F.P) for _ in range(3)] for _ in range(70)]
+    inputs[0] = [0, F.P - 1, 1]
+    inputs[1] = [F.P - 1, F.P - 1, F.P - 1]
+    check_tape(ops, consts, inputs, 4, 4, 4, [(0, 0, 0, True), (1, 0, 1, True), (69, 1, 5, True), (33, 3, 63, True),
+                                              (5, 2, 7, False)])
+
+
+def test_outputs_not_requested_and_empty_tape():
+    ops = [(F.OP_INPUT, O(F.K_NONE), O(F.K_INPUT, 0), O(F.K_NONE)), (F.OP_OUTPUT, 0, O(F.K_ACC), O(F.K_NONE)),
+           (F.OP_CHECK, O(F.K_ACC), O(F.K_ACC), O(F.K_ACC))]
+    inputs = [[5], [1], [0]]
+    outs, unsat, first, _ = run_lane(ops, [], inputs, 1, 0, 0, 0, want_outputs=False)
+    assert outs is None and unsat == 1 and first == 0  # 5*5 != 5
+    outs, unsat, first, _ = run_lane(ops, [], inputs, 1, 0, 0, 1, lane=1)
+    assert outs == [1] and unsat == 0 and first == 0xFFFFFFFF
+    outs, unsat, first, ln = run_lane([], [], inputs, 0, 0, 0, 0)
+    assert unsat == 0 and first == 0xFFFFFFFF and ln.steps < 80
+
+
+def test_strictness_of_the_model():
+    # an op that names a device slot beyond the region must trip the model, not pass silently
+    ops = [(F.OP_INPUT, O(F.K_GSLOT, 2), O(F.K_INPUT, 0), O(F.K_NONE))]
+    with pytest.raises(IM.ModelError):
+        run_lane(ops, [], [[3]], 0, 0, 2, 0)
+    ops = [(F.OP_COPY, O(F.K_NONE), O(F.K_LSLOT, 1), O(F.K_NONE))]
+    with pytest.raises(IM.ModelError):
+        run_lane(ops, [], [[3]], 0, 1, 0, 0)
+
+
+def _lowered(seed, statements, **opts):
+    from zkir_amd import api
+    g = api.default_generator_config()
+    g.min_instructions = g.max_instructions = statements
+    g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = 4, 1, 1, 1
+    g.no_loops, g.safe_array_index = 1, 1
+    lo = api.default_lower_options()
+    for k, v in opts.items():
+        setattr(lo, k, v)
+    return api.Lowerer(api.Generator(seed, g).generate(), lo).lower()
+
+
+@pytest.mark.parametrize("seed,statements,opts", [
+    (101, 60, {}),
+    (102, 120, {"n_lslots": 2}),
+    (103, 120, {"n_lslots": 0}),
+    (104, 90, {"use_acc": 0}),
+    (105, 150, {"n_lslots": 8, "window_lifetime": 8}),
+])
+def test_generated_circuits(seed, statements, opts):
+    tape = _lowered(seed, statements, **opts)
+    h = tape.hdr
+    ops, consts = tape.ops(), tape.consts()
+    assert all((c & 0xFF) in (0, 1, 2, 3, 4, 16, 17, 18, 48) for c, _, _, _ in ops)
+    rnd = random.Random(seed)
+    n_vec = 300
+    inputs = [[rnd.randrange(F.P) for _ in range(h.n_inputs)] for _ in range(n_vec)]
+    picks = [(0, 0, 0, True), (299, 0, 43, True), (rnd.randrange(n_vec), 2, 17, True), (77, 3, 63, False)]
+    check_tape(ops, consts, inputs, h.n_outputs, h.n_lslots, h.n_gslots, picks)
+
+
+def test_a_broken_witness_is_counted():
+    tape = _lowered(106, 80)
+    h = tape.hdr
+    ops, consts = tape.ops(), tape.consts()
+    # turn the first product into a sum: the constraints that use it stop holding
+    k = next(i for i, o in enumerate(ops) if (o[0] & 0xFF) == F.OP_MUL)
+    ops[k] = (F.OP_ADD,) + ops[k][1:]
+    rnd = random.Random(7)
+    inputs = [[rnd.randrange(F.P) for _ in range(h.n_inputs)] for _ in range(3)]
+    want_out, want_unsat = oracle(ops, consts, inputs[2], h.n_outputs)
+    assert want_unsat
+    got_out, unsat, first, _ = run_lane(ops, consts, inputs, h.n_outputs, h.n_lslots, h.n_gslots, 2, 1, 9)
+    assert got_out == want_out and unsat == len(want_unsat) and first == want_unsat[0]
+
+
+def test_inc_file_is_current():
+    path = os.path.join(ROOT, "zkir_amd", "csrc", "hip", "interp_core_asm.inc")
+    assert open(path).read() == G.render(G.build()), "run tools/gen_interp_asm.py"
+
+
+def test_register_discipline():
+    """Static checks over the text: no operand of the statement is ever a destination except
+    the two results in the last instructions; every named register is in the clobber list."""
+    import re
+    lines = [l for l in G.build() if not l.endswith(":")]
+    for i, l in enumerate(lines):
+        op, _, rest = l.partition(" ")
+        args = [x.strip() for x in rest.split(",")] if rest else []
+        writes_first = not (op.startswith("s_cmp") or op.startswith("s_cbranch") or op in ("s_branch", "s_nop", "s_waitcnt")
+                            or op.startswith("buffer_store") or op.startswith("ds_write"))
+        if writes_first and args and args[0].startswith("%["):
+            assert i >= len(lines) - 2 and args[0] in ("%[unsat]", "%[first]"), l
+        if op.startswith("v_") and len(args) > 1 and args[1].startswith("%[") and "_co_" in op:
+            raise AssertionError("carry destination is an operand: " + l)
+        for m in re.finditer(r"\bv(\d+)\b", l):
+            assert G.VB <= int(m.group(1)) <= G.V_LAST, l
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", l):
+            assert G.VB <= int(m.group(1)) and int(m.group(2)) <= G.V_LAST, l
+        for m in re.finditer(r"\bs(\d+)\b", l):
+            assert G.SB <= int(m.group(1)) <= G.S_LAST, l
+        for m in re.finditer(r"\bs\[(\d+):(\d+)\]", l):
+            assert G.SB <= int(m.group(1)) and int(m.group(2)) <= G.S_LAST, l

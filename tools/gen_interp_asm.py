@@ -1,0 +1,526 @@
+#!/usr/bin/env python3
+"""Emit zkir_amd/csrc/hip/interp_core_asm.inc: the gfx950 instruction stream that interprets
+one tape for one wavefront (64 input vectors), for tapes made of + - * and data movement.
+
+The stream is one asm statement inside zkir_interp_lean_kernel.  Its contract with the C++
+around it: every operand of the statement is read-only until the last three instructions
+(which write the two results), every register the stream writes is a physical register
+named in the clobber list, every memory access goes through a buffer descriptor with a
+byte count (the hardware drops accesses beyond it) or to LDS.
+
+Per op: the 16-byte op arrives by scalar load one op ahead; operands are fetched by kind
+(LDS window / device slot / constant pool / accumulator); + - * run on fixed registers,
+the product with the Montgomery stream of gen_fr_mul_asm.py; the result stays in the
+accumulator registers and is stored if the op names a destination.
+
+Slot layout (both LDS window and device slots): slot s occupies 8 KiB;
+  byte(s, wave, plane, lane) = s*8192 + wave*2048 + plane*1024 + lane*16
+plane 0 holds limbs 0..3, plane 1 limbs 4..7, so a wave reads or writes a plane as one
+1 KiB row.
+"""
+import os
+import sys
+
+P_LIMBS = [0xf0000001, 0x43e1f593, 0x79b97091, 0x2833e848, 0x8181585d, 0xb85045b6, 0xe131a029, 0x30644e72]
+R2_LIMBS = [0xae216da7, 0x1bb8e645, 0xe35c59e3, 0x53fe3ab1, 0x53bb8085, 0x8c49833d, 0x7f4e44a5, 0x0216d0b1]
+NP0 = 0xefffffff
+RSRC_WORD3 = 0x00020000  # raw buffer, 32-bit data format
+
+# ---- register plan ---------------------------------------------------------
+VB = 24  # first vector register of the stream (even: 64-bit operands must be even-aligned)
+E = lambda j: "v%d" % (VB + 2 * j) if j < 8 else "v%d" % (VB + 32)
+Z = lambda j: "v%d" % (VB + 2 * j + 1)
+EZ = lambda j: "v[%d:%d]" % (VB + 2 * j, VB + 2 * j + 1)
+L = lambda j: "v%d" % (VB + 16 + 2 * j)
+H = lambda j: "v%d" % (VB + 17 + 2 * j)
+D = lambda j: "v[%d:%d]" % (VB + 16 + 2 * j, VB + 17 + 2 * j)
+M = "v%d" % (VB + 33)
+
+
+def vreg8(base):
+    return ["v%d" % (base + j) for j in range(8)]
+
+
+def quad(base, half):
+    return "v[%d:%d]" % (base + 4 * half, base + 4 * half + 3)
+
+
+VA, VBB, VACC, VP = VB + 34, VB + 42, VB + 50, VB + 58
+A8, B8, ACC8, P8 = vreg8(VA), vreg8(VBB), vreg8(VACC), vreg8(VP)
+AD_A, AD_B, AD_C, FIRST, VT0, VT1 = ["v%d" % (VB + 66 + k) for k in range(6)]
+V_LAST = VB + 71
+
+SB = 48
+D_OPS, D_CST, D_GS, D_IO = ["s[%d:%d]" % (SB + 4 * k, SB + 4 * k + 3) for k in range(4)]
+d_word = lambda k, w: "s%d" % (SB + 4 * k + w)
+OP = ["s%d" % (SB + 16 + k) for k in range(4)]  # code, dst, a, b
+NX = "s[%d:%d]" % (SB + 20, SB + 23)
+OP_LO, OP_HI = "s[%d:%d]" % (SB + 16, SB + 17), "s[%d:%d]" % (SB + 18, SB + 19)
+NX_LO, NX_HI = "s[%d:%d]" % (SB + 20, SB + 21), "s[%d:%d]" % (SB + 22, SB + 23)
+REM, PCOFF = "s%d" % (SB + 24), "s%d" % (SB + 25)
+UNSAT, UNSAT_LO, UNSAT_HI = "s[%d:%d]" % (SB + 26, SB + 27), "s%d" % (SB + 26), "s%d" % (SB + 27)
+KCHK, CODE = "s%d" % (SB + 28), "s%d" % (SB + 29)
+CS = "s[%d:%d]" % (SB + 30, SB + 31)   # carry-out of the multiply-adds (never read)
+CC2 = "s[%d:%d]" % (SB + 32, SB + 33)  # a saved borrow / the failing lanes of a check
+T0, T1, T2, T3 = ["s%d" % (SB + 34 + k) for k in range(4)]
+SNP0, AACC, VMF, N32 = "s%d" % (SB + 38), "s%d" % (SB + 39), "s%d" % (SB + 40), "s%d" % (SB + 41)
+CST8 = "s[%d:%d]" % (SB + 44, SB + 51)
+cst_word = lambda j: "s%d" % (SB + 44 + j)
+S_LAST = SB + 51
+
+K_GSLOT, K_LSLOT, K_CONST, K_INPUT, K_ACC, K_NONE = 0, 1, 2, 3, 4, 5
+OP_INPUT, OP_OUTPUT, OP_COPY, OP_NEG, OP_ADD, OP_SUB, OP_MUL, OP_CHECK = 1, 2, 3, 4, 16, 17, 18, 48
+
+# operands of the asm statement (all inputs are read-only)
+IN_OPS, IN_NOPS, IN_CST, IN_NCST = "%[ops]", "%[n_ops]", "%[consts]", "%[n_consts]"
+IN_GS, IN_GSBYTES, IN_LDSB = "%[gslots]", "%[gslot_bytes]", "%[lds_base]"
+IN_INB, IN_OUTB = "%[in_base]", "%[out_base]"
+IN_N4, IN_LIVE = "%[n4]", "%[live]"
+IN_VLO, IN_VVEC = "%[v_lo]", "%[v_vec4]"
+OUT_UNSAT, OUT_FIRST = "%[unsat]", "%[first]"
+
+
+class Asm:
+    def __init__(self):
+        self.lines = []
+        self.n_label = 0
+
+    def e(self, s):
+        self.lines.append(s)
+
+    def label(self, name):
+        self.lines.append(name + ":")
+
+    def new(self, stem):
+        self.n_label += 1
+        return ".Lzk_%s_%d" % (stem, self.n_label)
+
+
+# ---- arithmetic streams -----------------------------------------------------
+def mul_stream(a, x, y, r):
+    """r = x*y*2^-256 mod p; x, y, r lists of 8 registers; r may alias x or y (the results
+    are written by the last eight instructions, after every read of x and y)."""
+    def mad(dst, u, v, addend):
+        a.e("v_mad_u64_u32 %s, %s, %s, %s, %s" % (dst, CS, u, v, addend))
+    for j in range(8):
+        a.e("v_mov_b32 %s, 0" % Z(j))
+    for i in range(8):
+        if i == 0:
+            for j in range(8):
+                mad(D(j), x[j], y[0], "0")
+        a.e("v_mov_b32 %s, %s" % (E(0), L(0)))
+        a.e("v_add_co_u32 %s, vcc, %s, %s" % (E(1), L(1), H(0)))
+        a.e("v_mul_lo_u32 %s, %s, %s" % (M, E(0), SNP0))
+        for j in range(2, 9):
+            if j < 8:
+                a.e("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (E(j), L(j), H(j - 1)))
+            else:
+                a.e("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (E(8), H(7)))
+            mad(D(j - 2), M, P8[j - 2], EZ(j - 2))
+        mad(D(7), M, P8[7], EZ(7))
+        a.e("v_add_co_u32 %s, vcc, %s, %s" % (E(0), L(1), H(0)))
+        if i < 7:
+            mad(D(0), x[0], y[i + 1], EZ(0))
+        else:
+            a.e("s_nop 0")
+        for j in range(2, 9):
+            if j < 8:
+                a.e("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (E(j - 1), L(j), H(j - 1)))
+            else:
+                a.e("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (E(7), E(8), H(7)))
+            if i < 7:
+                mad(D(j - 1), x[j - 1], y[i + 1], EZ(j - 1))
+            elif j < 8:
+                a.e("s_nop 0")
+    a.e("v_sub_co_u32 %s, vcc, %s, %s" % (L(0), E(0), P8[0]))
+    for j in range(1, 8):
+        a.e("s_nop 0")
+        a.e("v_subb_co_u32 %s, vcc, %s, %s, vcc" % (L(j), E(j), P8[j]))
+    a.e("s_nop 1")
+    for j in range(8):
+        a.e("v_cndmask_b32 %s, %s, %s, vcc" % (r[j], L(j), E(j)))
+
+
+def redc_stream(a, x):
+    """E(0..7) = x * 2^-256 mod p for x < p."""
+    for j in range(8):
+        a.e("v_mov_b32 %s, 0" % Z(j))
+    for j in range(8):
+        a.e("v_mov_b32 %s, %s" % (E(j), x[j]))
+    a.e("v_mul_lo_u32 %s, %s, %s" % (M, E(0), SNP0))
+    for j in range(8):
+        a.e("v_mad_u64_u32 %s, %s, %s, %s, %s" % (D(j), CS, M, P8[j], EZ(j)))
+    for i in range(8):
+        last = i == 7
+        a.e("v_add_co_u32 %s, vcc, %s, %s" % (E(0), L(1), H(0)))
+        a.e("s_nop 0" if last else "v_mul_lo_u32 %s, %s, %s" % (M, E(0), SNP0))
+        for j in range(2, 9):
+            if j < 8:
+                a.e("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (E(j - 1), L(j), H(j - 1)))
+            else:
+                a.e("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (E(7), H(7)))
+            if not last:
+                a.e("v_mad_u64_u32 %s, %s, %s, %s, %s" % (D(j - 2), CS, M, P8[j - 2], EZ(j - 2)))
+            elif j < 8:
+                a.e("s_nop 0")
+        if not last:
+            a.e("v_mad_u64_u32 %s, %s, %s, %s, %s" % (D(7), CS, M, P8[7], EZ(7)))
+
+
+def add_stream(a, x, y, r):
+    """r = x + y mod p."""
+    a.e("v_add_co_u32 %s, vcc, %s, %s" % (E(0), x[0], y[0]))
+    for j in range(1, 8):
+        a.e("s_nop 0")
+        a.e("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (E(j), x[j], y[j]))
+    a.e("s_nop 0")
+    a.e("v_sub_co_u32 %s, vcc, %s, %s" % (L(0), E(0), P8[0]))
+    for j in range(1, 8):
+        a.e("s_nop 0")
+        a.e("v_subb_co_u32 %s, vcc, %s, %s, vcc" % (L(j), E(j), P8[j]))
+    a.e("s_nop 1")
+    for j in range(8):  # borrow: the sum was below p
+        a.e("v_cndmask_b32 %s, %s, %s, vcc" % (r[j], L(j), E(j)))
+
+
+def sub_stream(a, x, y, r):
+    """r = x - y mod p."""
+    a.e("v_sub_co_u32 %s, vcc, %s, %s" % (E(0), x[0], y[0]))
+    for j in range(1, 8):
+        a.e("s_nop 0")
+        a.e("v_subb_co_u32 %s, vcc, %s, %s, vcc" % (E(j), x[j], y[j]))
+    a.e("s_nop 1")
+    a.e("s_mov_b64 %s, vcc" % CC2)
+    a.e("v_add_co_u32 %s, vcc, %s, %s" % (L(0), E(0), P8[0]))
+    for j in range(1, 8):
+        a.e("s_nop 0")
+        a.e("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (L(j), E(j), P8[j]))
+    for j in range(8):  # borrow: take the difference plus p
+        a.e("v_cndmask_b32_e64 %s, %s, %s, %s" % (r[j], E(j), L(j), CC2))
+
+
+# ---- operand access ----------------------------------------------------------
+def fetch(a, sop, dst_base, addr, acc_label=None, stem="f"):
+    """Issue the loads of the operand word in SGPR `sop` into v[dst_base..+7].
+    kind ACC: jump to acc_label if given (nothing loaded), else copy the accumulator.
+    Device-slot loads set VMF so the caller knows to wait on vmcnt."""
+    dst = vreg8(dst_base)
+    l_lds, l_glb, l_cst, l_done = a.new(stem + "lds"), a.new(stem + "glb"), a.new(stem + "cst"), a.new(stem + "done")
+    a.e("s_lshr_b32 %s, %s, 29" % (T0, sop))
+    a.e("s_and_b32 %s, %s, 0x1fffffff" % (T1, sop))
+    a.e("s_cmp_eq_u32 %s, %d" % (T0, K_LSLOT))
+    a.e("s_cbranch_scc1 %s" % l_lds)
+    a.e("s_cmp_eq_u32 %s, %d" % (T0, K_ACC))
+    if acc_label:
+        a.e("s_cbranch_scc1 %s" % acc_label)
+    else:
+        l_acc = a.new(stem + "acc")
+        a.e("s_cbranch_scc1 %s" % l_acc)
+    a.e("s_cmp_eq_u32 %s, %d" % (T0, K_GSLOT))
+    a.e("s_cbranch_scc1 %s" % l_glb)
+    a.e("s_cmp_eq_u32 %s, %d" % (T0, K_CONST))
+    a.e("s_cbranch_scc1 %s" % l_cst)
+    # any other kind reads as zero (the host validates tapes; this keeps the stream total)
+    for j in range(8):
+        a.e("v_mov_b32 %s, 0" % dst[j])
+    a.e("s_branch %s" % l_done)
+    if not acc_label:
+        a.label(l_acc)
+        if dst_base != VACC:
+            for j in range(8):
+                a.e("v_mov_b32 %s, %s" % (dst[j], ACC8[j]))
+        a.e("s_branch %s" % l_done)
+    a.label(l_cst)
+    a.e("s_lshl_b32 %s, %s, 5" % (T1, T1))
+    a.e("s_buffer_load_dwordx8 %s, %s, %s" % (CST8, D_CST, T1))
+    a.e("s_waitcnt lgkmcnt(0)")
+    for j in range(8):
+        a.e("v_mov_b32 %s, %s" % (dst[j], cst_word(j)))
+    a.e("s_branch %s" % l_done)
+    a.label(l_glb)
+    a.e("s_lshl_b32 %s, %s, 13" % (T1, T1))
+    a.e("v_add_u32 %s, %s, %s" % (addr, T1, IN_VLO))
+    a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen" % (quad(dst_base, 0), addr, D_GS))
+    a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:1024" % (quad(dst_base, 1), addr, D_GS))
+    a.e("s_mov_b32 %s, 1" % VMF)
+    a.e("s_branch %s" % l_done)
+    a.label(l_lds)
+    a.e("s_lshl_b32 %s, %s, 13" % (T1, T1))
+    a.e("s_add_u32 %s, %s, %s" % (T1, T1, IN_LDSB))
+    a.e("v_add_u32 %s, %s, %s" % (addr, T1, IN_VLO))
+    a.e("ds_read_b128 %s, %s" % (quad(dst_base, 0), addr))
+    a.e("ds_read_b128 %s, %s offset:1024" % (quad(dst_base, 1), addr))
+    a.label(l_done)
+
+
+def wait_loads(a):
+    """Wait for this op's operand loads: LDS and scalar always, vector memory only if a
+    device-slot load was issued (stores of earlier ops stay in flight otherwise)."""
+    skip = a.new("wskip")
+    a.e("s_waitcnt lgkmcnt(0)")
+    a.e("s_cmp_eq_u32 %s, 0" % VMF)
+    a.e("s_cbranch_scc1 %s" % skip)
+    a.e("s_waitcnt vmcnt(0)")
+    a.label(skip)
+
+
+def build():
+    a = Asm()
+    # ---- prologue ---------------------------------------------------------
+    def descriptor(k, base, nbytes_expr):
+        a.e("s_mov_b64 s[%d:%d], %s" % (SB + 4 * k, SB + 4 * k + 1, base))
+        a.e("s_and_b32 %s, %s, 0xffff" % (d_word(k, 1), d_word(k, 1)))
+        nbytes_expr(d_word(k, 2))
+        a.e("s_mov_b32 %s, 0x%08x" % (d_word(k, 3), RSRC_WORD3))
+    descriptor(0, IN_OPS, lambda w: a.e("s_lshl_b32 %s, %s, 4" % (w, IN_NOPS)))
+    descriptor(1, IN_CST, lambda w: a.e("s_lshl_b32 %s, %s, 5" % (w, IN_NCST)))
+    descriptor(2, IN_GS, lambda w: a.e("s_mov_b32 %s, %s" % (w, IN_GSBYTES)))
+    for j in range(8):
+        a.e("v_mov_b32 %s, 0x%08x" % (P8[j], P_LIMBS[j]))
+    for j in range(8):
+        a.e("v_mov_b32 %s, 0" % ACC8[j])
+    a.e("v_mov_b32 %s, -1" % FIRST)
+    a.e("s_mov_b64 %s, 0" % UNSAT)
+    a.e("s_mov_b32 %s, 0" % KCHK)
+    a.e("s_mov_b32 %s, 0x%08x" % (SNP0, NP0))
+    a.e("s_lshl_b32 %s, %s, 3" % (N32, IN_N4))
+    a.e("s_mov_b32 %s, %s" % (REM, IN_NOPS))
+    a.e("s_cmp_eq_u32 %s, 0" % REM)
+    a.e("s_cbranch_scc1 .Lzk_end")
+    a.e("s_buffer_load_dwordx4 %s, %s, 0" % (NX, D_OPS))
+    a.e("s_mov_b32 %s, 16" % PCOFF)
+
+    # ---- per-op loop --------------------------------------------------------
+    a.label(".Lzk_top")
+    a.e("s_waitcnt lgkmcnt(0)")
+    a.e("s_mov_b64 %s, %s" % (OP_LO, NX_LO))
+    a.e("s_mov_b64 %s, %s" % (OP_HI, NX_HI))
+    a.e("s_sub_u32 %s, %s, 1" % (REM, REM))
+    a.e("s_cmp_eq_u32 %s, 0" % REM)
+    a.e("s_cbranch_scc1 .Lzk_nopf")
+    a.e("s_buffer_load_dwordx4 %s, %s, %s" % (NX, D_OPS, PCOFF))
+    a.e("s_add_u32 %s, %s, 16" % (PCOFF, PCOFF))
+    a.label(".Lzk_nopf")
+    a.e("s_and_b32 %s, %s, 0xff" % (CODE, OP[0]))
+    a.e("s_mov_b32 %s, 0" % VMF)
+    a.e("s_cmp_lt_u32 %s, 16" % CODE)
+    a.e("s_cbranch_scc1 .Lzk_unary")
+
+    # binary ops and CHECK: fetch b, then a (or note that a is the accumulator)
+    fetch(a, OP[3], VBB, AD_B, stem="b")
+    a.e("s_mov_b32 %s, 0" % AACC)
+    fetch(a, OP[2], VA, AD_A, acc_label=".Lzk_a_is_acc", stem="a")
+    a.e("s_branch .Lzk_have_ab")
+    a.label(".Lzk_a_is_acc")
+    a.e("s_mov_b32 %s, 1" % AACC)
+    a.label(".Lzk_have_ab")
+    wait_loads(a)
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_MUL))
+    a.e("s_cbranch_scc1 .Lzk_mul")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_ADD))
+    a.e("s_cbranch_scc1 .Lzk_add")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_SUB))
+    a.e("s_cbranch_scc1 .Lzk_sub")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_CHECK))
+    a.e("s_cbranch_scc1 .Lzk_check")
+    a.e("s_branch .Lzk_next")  # an opcode this stream does not know: no effect
+
+    a.label(".Lzk_mul")
+    a.e("s_cmp_eq_u32 %s, 1" % AACC)
+    a.e("s_cbranch_scc1 .Lzk_mul_acc")
+    a.label(".Lzk_mul_ab")
+    mul_stream(a, A8, B8, ACC8)
+    a.e("s_branch .Lzk_store")
+    a.label(".Lzk_mul_acc")
+    mul_stream(a, ACC8, B8, ACC8)
+    a.e("s_branch .Lzk_store")
+
+    a.label(".Lzk_add")
+    a.e("s_cmp_eq_u32 %s, 1" % AACC)
+    a.e("s_cbranch_scc1 .Lzk_add_acc")
+    add_stream(a, A8, B8, ACC8)
+    a.e("s_branch .Lzk_store")
+    a.label(".Lzk_add_acc")
+    add_stream(a, ACC8, B8, ACC8)
+    a.e("s_branch .Lzk_store")
+
+    a.label(".Lzk_sub")
+    a.e("s_cmp_eq_u32 %s, 1" % AACC)
+    a.e("s_cbranch_scc1 .Lzk_sub_acc")
+    a.label(".Lzk_sub_ab")
+    sub_stream(a, A8, B8, ACC8)
+    a.e("s_branch .Lzk_store")
+    a.label(".Lzk_sub_acc")
+    sub_stream(a, ACC8, B8, ACC8)
+    a.e("s_branch .Lzk_store")
+
+    # CHECK: product into the a registers, then compare with c
+    a.label(".Lzk_check")
+    a.e("s_cmp_eq_u32 %s, 1" % AACC)
+    a.e("s_cbranch_scc1 .Lzk_check_acc")
+    mul_stream(a, A8, B8, A8)
+    a.e("s_branch .Lzk_check_cmp")
+    a.label(".Lzk_check_acc")
+    mul_stream(a, ACC8, B8, A8)
+    a.label(".Lzk_check_cmp")
+    a.e("s_mov_b32 %s, 0" % VMF)
+    fetch(a, OP[1], VBB, AD_C, acc_label=".Lzk_cmp_acc", stem="c")
+    wait_loads(a)
+
+    def compare(c):
+        a.e("v_xor_b32 %s, %s, %s" % (VT0, A8[0], c[0]))
+        a.e("v_xor_b32 %s, %s, %s" % (VT1, A8[1], c[1]))
+        for j in range(2, 8, 2):
+            a.e("v_xor_b32 %s, %s, %s" % (E(0), A8[j], c[j]))
+            a.e("v_xor_b32 %s, %s, %s" % (E(1), A8[j + 1], c[j + 1]))
+            a.e("v_or_b32 %s, %s, %s" % (VT0, VT0, E(0)))
+            a.e("v_or_b32 %s, %s, %s" % (VT1, VT1, E(1)))
+        a.e("v_or_b32 %s, %s, %s" % (VT0, VT0, VT1))
+        a.e("s_nop 0")
+        a.e("v_cmp_ne_u32 vcc, 0, %s" % VT0)
+    compare(B8)
+    a.e("s_branch .Lzk_cmp_count")
+    a.label(".Lzk_cmp_acc")
+    compare(ACC8)
+    a.label(".Lzk_cmp_count")
+    a.e("s_nop 1")
+    a.e("s_and_b64 %s, vcc, %s" % (CC2, IN_LIVE))
+    a.e("s_cbranch_scc0 .Lzk_cmp_ok")
+    a.e("s_bcnt1_i32_b64 %s, %s" % (T0, CC2))
+    a.e("s_add_u32 %s, %s, %s" % (UNSAT_LO, UNSAT_LO, T0))
+    a.e("s_addc_u32 %s, %s, 0" % (UNSAT_HI, UNSAT_HI))
+    a.e("v_mov_b32 %s, %s" % (VT0, KCHK))
+    a.e("v_mov_b32 %s, -1" % VT1)
+    a.e("v_cndmask_b32_e64 %s, %s, %s, %s" % (VT0, VT1, VT0, CC2))
+    a.e("v_min_u32 %s, %s, %s" % (FIRST, FIRST, VT0))
+    a.label(".Lzk_cmp_ok")
+    a.e("s_add_u32 %s, %s, 1" % (KCHK, KCHK))
+    a.e("s_branch .Lzk_next")
+
+    # ---- INPUT, OUTPUT, COPY, NEG ------------------------------------------
+    a.label(".Lzk_unary")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_OUTPUT))
+    a.e("s_cbranch_scc1 .Lzk_output")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_INPUT))
+    a.e("s_cbranch_scc1 .Lzk_input")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_COPY))
+    a.e("s_cbranch_scc1 .Lzk_copy")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_NEG))
+    a.e("s_cbranch_scc1 .Lzk_neg")
+    a.e("s_branch .Lzk_next")  # NOP and anything unknown
+
+    def io_descriptor(base, index_reg):
+        # element `index` of the tape's inputs (outputs): 8 limb rows of n vectors, 32*n bytes
+        a.e("s_mul_i32 %s, %s, %s" % (T2, index_reg, N32))
+        a.e("s_mul_hi_u32 %s, %s, %s" % (T3, index_reg, N32))
+        a.e("s_mov_b64 s[%d:%d], %s" % (SB + 12, SB + 13, base))
+        a.e("s_add_u32 %s, %s, %s" % (d_word(3, 0), d_word(3, 0), T2))
+        a.e("s_addc_u32 %s, %s, %s" % (d_word(3, 1), d_word(3, 1), T3))
+        a.e("s_and_b32 %s, %s, 0xffff" % (d_word(3, 1), d_word(3, 1)))
+        a.e("s_mov_b32 %s, %s" % (d_word(3, 2), N32))
+        a.e("s_mov_b32 %s, 0x%08x" % (d_word(3, 3), RSRC_WORD3))
+
+    def limb_offsets():
+        # byte offset of limb row j, one scalar register each (none is rewritten while a
+        # memory instruction that names it may still be reading it)
+        a.e("s_mov_b32 %s, 0" % cst_word(0))
+        for j in range(1, 8):
+            a.e("s_add_u32 %s, %s, %s" % (cst_word(j), cst_word(j - 1), IN_N4))
+
+    a.label(".Lzk_input")
+    a.e("s_and_b32 %s, %s, 0x1fffffff" % (T1, OP[2]))
+    io_descriptor(IN_INB, T1)
+    limb_offsets()
+    for j in range(8):
+        a.e("buffer_load_dword %s, %s, %s, %s offen" % (A8[j], IN_VVEC, D_IO, cst_word(j)))
+    for j in range(8):
+        a.e("v_mov_b32 %s, 0x%08x" % (B8[j], R2_LIMBS[j]))
+    a.e("s_waitcnt vmcnt(0)")
+    a.e("s_branch .Lzk_mul_ab")
+
+    a.label(".Lzk_output")
+    a.e("s_cmp_eq_u64 %s, 0" % IN_OUTB)  # nobody wants the outputs: skip the conversion too
+    a.e("s_cbranch_scc1 .Lzk_next")
+    fetch(a, OP[2], VA, AD_A, acc_label=".Lzk_out_acc", stem="o")
+    wait_loads(a)
+    redc_stream(a, A8)
+    a.e("s_branch .Lzk_out_store")
+    a.label(".Lzk_out_acc")
+    redc_stream(a, ACC8)
+    a.label(".Lzk_out_store")
+    io_descriptor(IN_OUTB, OP[1])
+    limb_offsets()
+    a.e("s_mov_b64 exec, %s" % IN_LIVE)
+    for j in range(8):
+        a.e("buffer_store_dword %s, %s, %s, %s offen" % (E(j), IN_VVEC, D_IO, cst_word(j)))
+    a.e("s_mov_b64 exec, -1")
+    a.e("s_branch .Lzk_next")
+
+    a.label(".Lzk_copy")
+    fetch(a, OP[2], VACC, AD_A, stem="k")
+    wait_loads(a)
+    a.e("s_branch .Lzk_store")
+
+    a.label(".Lzk_neg")  # 0 - a
+    fetch(a, OP[2], VBB, AD_B, stem="n")
+    for j in range(8):
+        a.e("v_mov_b32 %s, 0" % A8[j])
+    wait_loads(a)
+    a.e("s_branch .Lzk_sub_ab")
+
+    # ---- store the accumulator where the op says ---------------------------
+    a.label(".Lzk_store")
+    a.e("s_lshr_b32 %s, %s, 29" % (T0, OP[1]))
+    a.e("s_and_b32 %s, %s, 0x1fffffff" % (T1, OP[1]))
+    a.e("s_lshl_b32 %s, %s, 13" % (T1, T1))
+    a.e("s_cmp_eq_u32 %s, %d" % (T0, K_LSLOT))
+    a.e("s_cbranch_scc1 .Lzk_st_lds")
+    a.e("s_cmp_eq_u32 %s, %d" % (T0, K_GSLOT))
+    a.e("s_cbranch_scc0 .Lzk_next")
+    a.e("v_add_u32 %s, %s, %s" % (AD_C, T1, IN_VLO))
+    a.e("buffer_store_dwordx4 %s, %s, %s, 0 offen" % (quad(VACC, 0), AD_C, D_GS))
+    a.e("buffer_store_dwordx4 %s, %s, %s, 0 offen offset:1024" % (quad(VACC, 1), AD_C, D_GS))
+    a.e("s_nop 1")
+    a.e("s_branch .Lzk_next")
+    a.label(".Lzk_st_lds")
+    a.e("s_add_u32 %s, %s, %s" % (T1, T1, IN_LDSB))
+    a.e("v_add_u32 %s, %s, %s" % (AD_C, T1, IN_VLO))
+    a.e("ds_write_b128 %s, %s" % (AD_C, quad(VACC, 0)))
+    a.e("ds_write_b128 %s, %s offset:1024" % (AD_C, quad(VACC, 1)))
+    a.label(".Lzk_next")
+    a.e("s_cmp_lg_u32 %s, 0" % REM)
+    a.e("s_cbranch_scc1 .Lzk_top")
+
+    a.label(".Lzk_end")
+    a.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    a.e("s_mov_b64 %s, %s" % (OUT_UNSAT, UNSAT))
+    a.e("v_mov_b32 %s, %s" % (OUT_FIRST, FIRST))
+    return a.lines
+
+
+def clobbers():
+    v = ['"v%d"' % k for k in range(VB, V_LAST + 1)]
+    s = ['"s%d"' % k for k in range(SB, S_LAST + 1)]
+    return ", ".join(v + s + ['"vcc"', '"scc"', '"memory"'])
+
+
+def render(lines):
+    out = ["// generated by tools/gen_interp_asm.py -- do not edit",
+           "// vector registers v%d..v%d, scalar registers s%d..s%d" % (VB, V_LAST, SB, S_LAST),
+           "#define ZKIR_INTERP_CORE_ASM \\"]
+    for l in lines:
+        out.append('  "%s\\n" \\' % l)
+    out.append("")
+    out.append("#define ZKIR_INTERP_CORE_CLOBBERS %s" % clobbers())
+    out.append("#define ZKIR_INTERP_CORE_VGPR_LAST %d" % V_LAST)
+    return "\n".join(out) + "\n"
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "zkir_amd", "csrc", "hip", "interp_core_asm.inc")
+    lines = build()
+    with open(path, "w") as f:
+        f.write(render(lines))
+    n_valu = sum(1 for l in lines if l.startswith("v_"))
+    print("wrote %s: %d lines, %d vector ALU instructions" % (path, len(lines), n_valu))

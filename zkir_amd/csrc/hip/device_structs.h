@@ -18,7 +18,8 @@ struct TapeDesc {
   uint32_t n_inputs;
   uint32_t n_outputs;
   uint32_t n_constraints;
-  uint64_t reserved[2];
+  uint32_t n_consts;
+  uint32_t reserved[3];
 };
 static_assert(sizeof(TapeDesc) == 64, "TapeDesc must stay 64 bytes");
 

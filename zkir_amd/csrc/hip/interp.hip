@@ -337,6 +337,66 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
   }
 }
 
+// ---- the lean interpreter ---------------------------------------------------
+// Same work-item loop, same results, for tapes made of + - * and data movement; the per-op
+// loop is one generated instruction stream (tools/gen_interp_asm.py) instead of compiled
+// C++: operands land directly in the registers the multiplier reads, an accumulator operand
+// costs nothing, and a wait on vector memory is issued only by an op that loaded from it.
+// Every access the stream makes goes through a buffer descriptor carrying the byte count of
+// the region (tape, constants, this workgroup's slots, one input or output element), or to
+// LDS.  Slot layout differs from the C++ kernels (which is fine: slots do not outlive a work
+// item): slot s, wave w, plane h, lane l at s*8192 + w*2048 + h*1024 + l*16.
+// Limits the host checks before choosing this kernel: 32 * n_vectors < 2^32.
+#include "interp_core_asm.inc"
+
+__global__ void __launch_bounds__(kBlock, 2)
+zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_t passes_per_tape,
+                        uint64_t n_vectors, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ outputs,
+                        uint4* __restrict__ gslot_pool, uint32_t gslots_per_block,
+                        uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats,
+                        uint32_t* __restrict__ work_counter) {
+  __shared__ uint32_t next_item;
+  const uint64_t gslots = (uint64_t)(uintptr_t)(gslot_pool + (size_t)blockIdx.x * gslots_per_block * 2 * kBlock);
+  const uint32_t gslot_bytes = gslots_per_block * (uint32_t)(2 * kBlock * sizeof(uint4));
+  // the low half of a generic pointer into LDS is the LDS byte address
+  const uint32_t lds_base = (uint32_t)(uintptr_t)zkir_lds_slots;
+  const uint32_t v_lo = (threadIdx.x >> 6) * 2048u + (threadIdx.x & 63u) * 16u;
+  const uint32_t n4 = (uint32_t)n_vectors * 4u;
+
+  const uint64_t total = (uint64_t)n_tapes * passes_per_tape;
+  for (;;) {
+    if (threadIdx.x == 0) next_item = atomicAdd(work_counter, 1u);
+    __syncthreads();
+    const uint64_t w = next_item;
+    __syncthreads();
+    if (w >= total) break;
+    const uint32_t tape_i = (uint32_t)(w / passes_per_tape);
+    const uint32_t pass = (uint32_t)(w % passes_per_tape);
+    const TapeDesc td = ((uniform_desc_t)tapes)[tape_i];
+    const uint64_t vec = (uint64_t)pass * kBlock + threadIdx.x;
+    const bool live = vec < n_vectors;
+    const uint32_t v_vec4 = live ? (uint32_t)vec * 4u : 0u;  // idle lanes recompute vector 0 and report nothing
+    const uint64_t live_mask = __ballot(live);
+    const uint64_t ops = (uint64_t)(uintptr_t)td.ops, consts = (uint64_t)(uintptr_t)td.consts;
+    const uint64_t in_base = (uint64_t)(uintptr_t)(inputs + td.in_word_off);
+    const uint64_t out_base = outputs ? (uint64_t)(uintptr_t)(outputs + td.out_word_off) : 0;  // 0: not wanted
+
+    uint64_t wave_unsat;
+    uint32_t first_bad;
+    asm volatile(ZKIR_INTERP_CORE_ASM
+                 : [unsat] "=s"(wave_unsat), [first] "=v"(first_bad)
+                 : [ops] "s"(ops), [n_ops] "s"(td.n_ops), [consts] "s"(consts), [n_consts] "s"(td.n_consts),
+                   [gslots] "s"(gslots), [gslot_bytes] "s"(gslot_bytes), [lds_base] "s"(lds_base),
+                   [in_base] "s"(in_base), [out_base] "s"(out_base), [n4] "s"(n4), [live] "s"(live_mask), [v_lo] "v"(v_lo), [v_vec4] "v"(v_vec4)
+                 : ZKIR_INTERP_CORE_CLOBBERS);
+
+    if ((threadIdx.x & 63) == 0 && wave_unsat)
+      atomicAdd((unsigned long long*)&unsat_per_tape[tape_i], (unsigned long long)wave_unsat);
+    if (live && first_bad != 0xffffffffu)
+      atomicMin((unsigned long long*)&stats[0], (unsigned long long)((vec << 32) | first_bad));
+  }
+}
+
 // constants arrive canonical; rewrite them in Montgomery form in place
 __global__ void zkir_consts_to_mont_kernel(uint32_t* consts, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -403,33 +463,36 @@ __global__ void __launch_bounds__(256) zkir_fr_mul_rate_kernel(uint32_t* out, ui
 // ---- host-callable launchers (C++ linkage, used by runtime.cpp) ------------
 namespace zkir {
 
-hipError_t launch_interp(bool full, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
+// variant: 0 = + - * tapes (compiled), 1 = every operator (compiled), 2 = + - * tapes (generated stream)
+static const void* interp_entry(int variant) {
+  switch (variant) {
+    case 1: return (const void*)zkir_interp_kernel<true>;
+    case 2: return (const void*)zkir_interp_lean_kernel;
+    default: return (const void*)zkir_interp_kernel<false>;
+  }
+}
+
+hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
                          uint32_t* work_counter, uint32_t grid, hipStream_t stream) {
   const size_t lds_bytes = (size_t)lslots * 2 * kBlock * sizeof(uint4);
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  if (variant == 2 && n_vectors * 32 >= (1ull << 32)) return hipErrorInvalidValue;
   if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS limit the kernel must opt in
-    hipError_t e = hipFuncSetAttribute(full ? (const void*)zkir_interp_kernel<true> : (const void*)zkir_interp_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute(interp_entry(variant), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
-  if (full)
-    hipLaunchKernelGGL(zkir_interp_kernel<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, tapes_dev, n_tapes,
-                       passes_per_tape, n_vectors, inputs, outputs, (uint4*)gslot_pool, gslots_per_block,
-                       unsat_per_tape, stats, work_counter);
-  else
-    hipLaunchKernelGGL(zkir_interp_kernel<false>, dim3(grid), dim3(kBlock), lds_bytes, stream, tapes_dev, n_tapes,
-                       passes_per_tape, n_vectors, inputs, outputs, (uint4*)gslot_pool, gslots_per_block,
-                       unsat_per_tape, stats, work_counter);
-  return hipGetLastError();
+  uint4* pool = (uint4*)gslot_pool;
+  void* args[] = {&tapes_dev, &n_tapes, &passes_per_tape, &n_vectors, &inputs, &outputs, &pool, &gslots_per_block,
+                  &unsat_per_tape, &stats, &work_counter};
+  return hipLaunchKernel(interp_entry(variant), dim3(grid), dim3(kBlock), args, lds_bytes, stream);
 }
 
 // workgroups of the interpreter that fit on one CU with `lslots` window slots
-hipError_t interp_blocks_per_cu(bool full, uint32_t lslots, int* blocks) {
+hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, int* blocks) {
   const size_t lds_bytes = (size_t)lslots * 2 * kBlock * sizeof(uint4);
-  hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, zkir_interp_kernel<true>, kBlock, lds_bytes)
-                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, zkir_interp_kernel<false>, kBlock, lds_bytes);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, interp_entry(variant), kBlock, lds_bytes);
   if (e == hipSuccess && *blocks < 1) *blocks = 1;
   return e;
 }

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -16,11 +17,11 @@
 #include "tape_check.h"
 
 namespace zkir {
-hipError_t launch_interp(bool full, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
+hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
                          uint32_t* work_counter, uint32_t grid, hipStream_t stream);
-hipError_t interp_blocks_per_cu(bool full, uint32_t lslots, int* blocks);
+hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, int* blocks);
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream);
 hipError_t launch_int_mul_rate(int which, uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
 hipError_t launch_fr_mul_rate(uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
@@ -89,11 +90,21 @@ int32_t ensure(zkir_ctx* ctx, void** buf, size_t* have, size_t need) {
 // Grid: as many workgroups as the machine holds at once (the occupancy the kernel's
 // registers and the LDS window allow), never more than there is work; each workgroup
 // then walks the work items with a grid stride and reuses its slot region.
-uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, bool full, uint32_t lslots) {
+uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, int variant, uint32_t lslots) {
   int per_cu = 2;
-  if (zkir::interp_blocks_per_cu(full, lslots, &per_cu) != hipSuccess) per_cu = 2;
+  if (zkir::interp_blocks_per_cu(variant, lslots, &per_cu) != hipSuccess) per_cu = 2;
   const uint64_t g = (uint64_t)ctx->n_cu * (uint64_t)per_cu;
   return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, work_items));
+}
+
+// Which interpreter kernel runs a launch: 1 when a tape uses an operator beyond + - *,
+// otherwise the compiled kernel (0) unless ZKIR_INTERP=lean selects the generated
+// instruction stream (2), which also needs 32*N to fit 32 bits.
+int pick_variant(bool full, uint64_t N) {
+  if (full) return 1;
+  const char* want = std::getenv("ZKIR_INTERP");
+  const bool lean = want && std::strcmp(want, "lean") == 0;
+  return (lean && N * 32 < (1ull << 32)) ? 2 : 0;
 }
 
 struct Launch {
@@ -119,6 +130,7 @@ int32_t build_launch(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, uint64_
     d.n_inputs = t.hdr.n_inputs;
     d.n_outputs = t.hdr.n_outputs;
     d.n_constraints = t.hdr.n_constraints;
+    d.n_consts = t.hdr.n_consts;
     in_off += (uint64_t)t.hdr.n_inputs * 8 * N;
     out_off += (uint64_t)t.hdr.n_outputs * 8 * N;
     L->full = L->full || t.full;
@@ -140,7 +152,8 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
   const uint32_t passes = (uint32_t)((N + ZKIR_BLOCK_THREADS - 1) / ZKIR_BLOCK_THREADS);
   const uint64_t work = (uint64_t)n * passes;
   if (work >= (1ull << 32) - (1u << 20)) return fail(ctx, ZKIR_E_LIMIT, "too many (tape, pass) work items for one launch");
-  const uint32_t grid = pick_grid(ctx, work, L.full, L.max_lslots);
+  const int variant = pick_variant(L.full, N);
+  const uint32_t grid = pick_grid(ctx, work, variant, L.max_lslots);
   const size_t slot_bytes = (size_t)2 * ZKIR_BLOCK_THREADS * 16;
   rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, (size_t)grid * L.max_gslots * slot_bytes);
   if (rc) return rc;
@@ -150,7 +163,7 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
   // L.descs is pageable host memory: hipMemcpyAsync has consumed it when it returns,
   // and the device-side staging buffer is only rewritten by later work on `stream`.
   HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, 256, stream));
-  hipError_t e = zkir::launch_interp(L.full, (const TapeDesc*)ctx->desc_buf, n, passes, N, in_dev, out_dev, ctx->gslot_pool,
+  hipError_t e = zkir::launch_interp(variant, (const TapeDesc*)ctx->desc_buf, n, passes, N, in_dev, out_dev, ctx->gslot_pool,
                                      L.max_gslots, L.max_lslots, unsat_dev, stats_dev, (uint32_t*)ctx->work_counter,
                                      grid, stream);
   if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
