@@ -31,6 +31,23 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True, params=["generated-stream", "compiled"])
+def interpreter_kernel(request):
+    """Every test runs twice: + - * tapes through the generated instruction stream (the
+    default) and through the compiled kernel (ZKIR_INTERP=compiled); tapes with other
+    operators take the compiled every-operator kernel either way."""
+    old = os.environ.get("ZKIR_INTERP")
+    if request.param == "compiled":
+        os.environ["ZKIR_INTERP"] = "compiled"
+    else:
+        os.environ.pop("ZKIR_INTERP", None)
+    yield request.param
+    if old is None:
+        os.environ.pop("ZKIR_INTERP", None)
+    else:
+        os.environ["ZKIR_INTERP"] = old
+
+
 def hand_tape(ops, consts, n_inputs, n_outputs, n_g, n_l):
     n_con = sum(1 for o in ops if o[0] == F.OP_CHECK)
     hdr = api.TapeHdr(0x31544B5A, 1, n_inputs, n_outputs, len(consts), len(ops), n_g, n_l, n_con, 0, 0)

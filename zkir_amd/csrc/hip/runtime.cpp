@@ -97,14 +97,15 @@ uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, int variant, uint32
   return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, work_items));
 }
 
-// Which interpreter kernel runs a launch: 1 when a tape uses an operator beyond + - *,
-// otherwise the compiled kernel (0) unless ZKIR_INTERP=lean selects the generated
-// instruction stream (2), which also needs 32*N to fit 32 bits.
+// Which interpreter kernel runs a launch: 1 (compiled, every operator) when a tape uses an
+// operator beyond + - *; otherwise 2, the generated instruction stream, which needs 32*N to
+// fit 32 bits; otherwise 0, the compiled + - * kernel.  ZKIR_INTERP=compiled in the
+// environment forces the compiled kernels (a debugging aid: all three give the same bits).
 int pick_variant(bool full, uint64_t N) {
   if (full) return 1;
   const char* want = std::getenv("ZKIR_INTERP");
-  const bool lean = want && std::strcmp(want, "lean") == 0;
-  return (lean && N * 32 < (1ull << 32)) ? 2 : 0;
+  if (want && std::strcmp(want, "compiled") == 0) return 0;
+  return N * 32 < (1ull << 32) ? 2 : 0;
 }
 
 struct Launch {
