@@ -162,6 +162,16 @@ def main():
         fr_peak = ctx.fr_mul_rate()
         achieved = 128.0 * fr_muls / (kernel_ms * 1e-3)
         alg_bytes = (32 * (h.n_inputs + (0 if gadget else h.n_outputs)) + 4) * n
+        # HBM bytes per launch from the counter passes committed under profiles/ (only for the
+        # exact workload they were taken on; counters cannot be read from inside this process)
+        traffic = None
+        if (not gadget and args.signal_window == 0 and args.log2_vectors == LOG2_VECTORS and h.n_lslots == 4
+                and not os.environ.get("ZKIR_INTERP")):
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                    traffic = json.load(f)["config2_seed%d_2^%d_window4" % (WORKLOAD_SEED, LOG2_VECTORS)]["bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                traffic = None
         line = {
             "metric": "R1CS constraint checks/sec over BN254 Fr",
             "value": value,
@@ -187,13 +197,14 @@ def main():
             },
             "fr_mul_per_s": fr_muls * world / (1e3 * elapsed / args.steps * 1e-3),
             "roofline": {
-                "kernel": "zkir_interp_kernel",
+                "kernel": ("zkir_interp_kernel" if os.environ.get("ZKIR_INTERP") == "compiled"
+                           else "zkir_interp_lean_kernel"),
                 "bound": "int32_mulhi",
                 "achieved": achieved / 1e12,
                 "peak": mulhi_peak / 1e12,
                 "unit": "Tmulhi/s",
                 "frac": achieved / mulhi_peak,
-                "traffic": None,
+                "traffic": traffic,
                 "peak_source": "measured on this device (v_mul_hi_u32 issue-rate probe); theoretical %.1f" % (MULHI_PEAK_THEORETICAL / 1e12),
                 "frac_of_theoretical": achieved / MULHI_PEAK_THEORETICAL,
                 "kernel_ms": kernel_ms,
@@ -202,7 +213,8 @@ def main():
             },
             "roofline_hbm": {
                 "bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
