@@ -145,8 +145,9 @@ typedef struct zkir_tape_hdr {
  *                                            (src/rng.rs:11-53, src/generator.rs:124-164)
  *   zkir_circuit_transpile_circom <-> CircomTranspiler::new + transpile_circuit
  *                                            (src/circom.rs:10-15, :412-429)
- * Circuits cross the ABI as an s-expression text form of the AST (see
- * INTEGRATION.md); the Rust side would serialise its own `Circuit` to it.
+ * Circuits cross the ABI as an s-expression text form of the AST (grammar at
+ * the top of zkir_amd/csrc/host/sexpr.hpp); the Rust side would serialise its
+ * own `Circuit` to it.
  */
 typedef struct zkir_circuit zkir_circuit;
 typedef struct zkir_tape zkir_tape;

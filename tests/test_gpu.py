@@ -239,6 +239,43 @@ def test_many_tapes_one_launch(ctx):
         ctx.release(t)
 
 
+def test_campaign_on_one_gpu():
+    """The campaign driver with the real evaluator: generated circuits satisfy their own
+    constraints for every device-drawn vector, refused circuits are counted by class, and a
+    hand-broken tape among them is reported as divergent."""
+    from zkir_amd import campaign
+
+    def config_of(cid):
+        g = campaign.campaign_config(cid, min_constraints=8, max_constraints=120)
+        if cid % 6 == 0:  # keep the reference's loops in some: lower refuses most of those
+            g.no_loops, g.quadratic_aware = 0, 0
+        return g
+
+    o = z.default_lower_options()
+    o.max_iterations = 200
+    ev = campaign.GpuEvaluator(0, input_seed=5)
+    res = campaign.run_local(range(40), 31, 300, ev, config_of=config_of, lower_options=o, group=7)
+    tot = campaign.reduce_results(res)
+    assert tot["circuits"] == 40 and tot["rejected"] == sum(tot["classes"][1:]) and 0 < tot["rejected"] < 40
+    assert tot["unsat"] == 0 and tot["divergent"] == [] and tot["checks"] > 0
+
+    def breaking(tapes, n_vectors, ids):  # turn one circuit's first product into a sum
+        tapes = list(tapes)
+        for k, cid in enumerate(ids):
+            if cid == 13:
+                ops = tapes[k].ops()
+                j = next(i for i, op in enumerate(ops) if op[0] == F.OP_MUL)
+                ops[j] = (F.OP_ADD,) + ops[j][1:]
+                blob = tapes[k].blob()
+                blob = b"".join(struct.pack("<4I", *op) for op in ops) + blob[16 * len(ops):]
+                tapes[k] = z.Tape.from_parts(tapes[k].hdr, blob)
+        return ev(tapes, n_vectors, ids)
+
+    res = campaign.run_local(range(40), 31, 300, breaking, config_of=config_of, lower_options=o, group=7)
+    assert res.divergent == [13] and res.unsat > 0
+    ev.close()
+
+
 def test_gadget_chain(ctx):
     c = z.poseidon_style_gadget(4, 60, 5)
     tape = z.Lowerer(c).lower()

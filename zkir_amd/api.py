@@ -153,7 +153,7 @@ class Circuit:
         self._h = c_void_p(handle) if not isinstance(handle, c_void_p) else handle
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # lib is gone when the interpreter shuts down
             lib.zkir_circuit_free(self._h)
             self._h = None
 
@@ -212,7 +212,7 @@ class Tape:
         _host_check(lib.zkir_tape_header(self._h, byref(self.hdr)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.zkir_tape_free(self._h)
             self._h = None
 
@@ -296,7 +296,7 @@ class Context:
         self._tapes = {}
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.zkir_ctx_destroy(self._h)
             self._h = None
 

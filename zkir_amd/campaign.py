@@ -48,17 +48,24 @@ def _lower_one(args):
         return cid, e.status_class, None, None
 
 
-def lower_parallel(circuit_ids, base_seed, processes=8):
-    """Generate and lower campaign circuits on `processes` host cores (the generator keeps the
-    reference's linear scans over the scope, so large circuits cost host time); yields
-    (circuit id, class, Tape or None) in id order."""
+def lower_parallel(circuit_ids, base_seed, processes=8, pool=None):
+    """Generate and lower campaign circuits on `processes` host cores; yields
+    (circuit id, class, Tape or None) in id order.  Pass a `pool` made before the process
+    touched the GPU when the caller evaluates on one (workers are forked)."""
     import multiprocessing as mp
-    with mp.get_context("fork").Pool(processes) as pool:
+    own = pool is None
+    if own:
+        pool = mp.get_context("fork").Pool(processes)
+    try:
         for cid, cls, hdr, blob in pool.imap(_lower_one, [(c, base_seed) for c in circuit_ids], chunksize=4):
             if hdr is None:
                 yield cid, cls, None
             else:
                 yield cid, cls, api.Tape.from_parts(api.TapeHdr.from_buffer_copy(hdr), blob)
+    finally:
+        if own:
+            pool.close()
+            pool.join()
 
 
 class LocalResult:
@@ -75,8 +82,12 @@ class LocalResult:
 
 
 def run_local(circuit_ids, base_seed, n_vectors, evaluate, config_of=campaign_config, lower_options=None,
-              expected_class=None, group=64):
+              expected_class=None, group=64, lowered=None):
     """Generate, lower and evaluate the circuits of one rank.
+
+    lowered: optional iterator of (circuit id, class, Tape or None) for circuit_ids in order
+    (lower_parallel makes one on several host cores); without it circuits are generated and
+    lowered here, one after the other.
 
     evaluate(tapes, n_vectors, circuit_ids) -> (per-tape unsat list, faults) runs a group of
     lowered tapes for n_vectors fresh random vectors each; on a GPU rank it is
@@ -102,14 +113,16 @@ def run_local(circuit_ids, base_seed, n_vectors, evaluate, config_of=campaign_co
             res.divergent.extend(ids[:1])  # a fault is reported per launch: flag the group's first circuit
         pending.clear()
 
-    for cid in circuit_ids:
+    def lower_here():
+        for cid in circuit_ids:
+            circuit = api.Generator(circuit_seed(base_seed, cid), config_of(cid)).generate()
+            try:
+                yield cid, 0, api.Lowerer(circuit, lower_options).lower()
+            except api.LowerRejected as e:
+                yield cid, e.status_class, None
+
+    for cid, cls, tape in (lowered if lowered is not None else lower_here()):
         res.circuits += 1
-        circuit = api.Generator(circuit_seed(base_seed, cid), config_of(cid)).generate()
-        cls = 0
-        try:
-            tape = api.Lowerer(circuit, lower_options).lower()
-        except api.LowerRejected as e:
-            cls, tape = e.status_class, None
         res.classes[cls] += 1
         if expected_class is not None and cid in expected_class and expected_class[cid] != api.LOWER_CLASSES[cls]:
             res.divergent.append(cid)
@@ -188,3 +201,61 @@ def reduce_results(res, dist=None, device=None, capacity=4096):
     tot = [int(v) for v in t.cpu()]
     return {"circuits": tot[0], "rejected": tot[1], "checks": tot[2], "unsat": tot[3], "faults": tot[4],
             "n_divergent": tot[5], "classes": tot[6:], "divergent": sorted(set(union))}
+
+
+def main(argv=None):
+    """A differential campaign on the GPUs of one node: one rank per GPU under
+    `python -m torch.distributed.run --nproc-per-node G -m zkir_amd.campaign ...`, or a single
+    process.  Rank 0 prints one JSON line with the job-wide totals."""
+    import argparse
+    import json
+    import multiprocessing as mp
+    import os
+    import time
+
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--circuits", type=int, default=1024)
+    ap.add_argument("--vectors", type=int, default=1024, help="input vectors per circuit")
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--group", type=int, default=512, help="circuits per launch")
+    ap.add_argument("--processes", type=int, default=8, help="host processes that generate and lower, per rank")
+    args = ap.parse_args(argv)
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    pool = mp.get_context("fork").Pool(args.processes)  # forked before anything touches the GPU
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    ev = GpuEvaluator(local_rank, input_seed=args.seed + rank)
+    ids = shard(args.circuits, rank, world)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run_local(ids, args.seed, args.vectors, ev, group=args.group,
+                    lowered=lower_parallel(ids, args.seed, pool=pool))
+    tot = reduce_results(res, dist if world > 1 else None, device)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    pool.close()
+    pool.join()
+    if rank == 0:
+        tot.update({"n_gpus": world, "seconds": float(t.item()), "vectors_per_circuit": args.vectors,
+                    "checks_per_s": tot["checks"] / float(t.item()), "circuits_per_s": tot["circuits"] / float(t.item()),
+                    "classes": {api.LOWER_CLASSES[k]: v for k, v in enumerate(tot["classes"]) if v}})
+        print(json.dumps(tot), flush=True)
+    ev.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

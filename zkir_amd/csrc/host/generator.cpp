@@ -378,23 +378,39 @@ std::optional<Expr> Generator::gen_var_ref(size_t) {
 std::optional<Expr> Generator::gen_constant(size_t) { return Expr::Constant(std::to_string(rng_.next())); }
 
 std::optional<Expr> Generator::gen_array_index(size_t) {
-  std::vector<std::pair<VarRef, size_t>> vars;
-  for (size_t k = 0, n = scope_stack_.touched_arrays.count(); k < n; k++) {
-    const Variable* v = &scope_stack_.flat[scope_stack_.touched_arrays.select(k)];
-    const std::vector<size_t> indices = v->get_initialized();
-    // a position in 0..=len, not one of `indices` (generator.rs:584): it can name an
-    // unwritten element, or one past the end when every element is written
-    size_t idx = rng_.rand(0, indices.size());
-    if (cfg_.safe_array_index) idx = indices[idx % indices.size()];  // extension: always a written element
-    vars.emplace_back(v->var_ref, idx);
+  // One draw per array that has a written element, in scope order, then one draw to choose
+  // among them (generator.rs:572-601); only the chosen array's draw is used, but every draw
+  // must be made to keep the random stream aligned with the reference.
+  const size_t n = scope_stack_.touched_arrays.count();
+  size_t chosen_pos = 0, chosen_idx = 0;
+  array_draws_.clear();
+  for (size_t k = 0; k < n; k++) {
+    const Variable& v = scope_stack_.flat[scope_stack_.touched_arrays.select(k)];
+    size_t written = 0;
+    for (bool b : v.initialized) written += b;
+    // a position in 0..=written, not one of the written elements (generator.rs:584): it can
+    // name an unwritten element, or one past the end when every element is written
+    array_draws_.push_back(rng_.rand(0, written));
   }
-  if (const auto* pick = rng_.rand_vec(vars)) {
-    VarRef r;
-    r.id = pick->first.id;
-    r.idx = pick->second;
-    return Expr::Var(r);
+  if (n == 0) return std::nullopt;
+  const size_t pick = rng_.rand(0, n - 1);
+  chosen_pos = scope_stack_.touched_arrays.select(pick);
+  chosen_idx = array_draws_[pick];
+  const Variable& v = scope_stack_.flat[chosen_pos];
+  if (cfg_.safe_array_index) {  // extension: always a written element
+    size_t written = 0;
+    for (bool b : v.initialized) written += b;
+    size_t want = chosen_idx % written, seen = 0;
+    for (size_t i = 0; i < v.initialized.size(); i++)
+      if (v.initialized[i] && seen++ == want) {
+        chosen_idx = i;
+        break;
+      }
   }
-  return std::nullopt;
+  VarRef r;
+  r.id = v.var_ref.id;
+  r.idx = chosen_idx;
+  return Expr::Var(r);
 }
 
 // ---- extensions (no counterpart in the reference) ----
