@@ -222,8 +222,11 @@ def main():
             sample = (64 if gadget else 8192) * threads  # a few seconds of work per thread
             inp_s = np.ascontiguousarray(inp[:, :, :sample].cpu().numpy().view(np.uint32))
             cps, dt = cpu_baseline(tape, inp_s, threads)
+            one = max(1, sample // threads)
+            cps1, dt1 = cpu_baseline(tape, np.ascontiguousarray(inp_s[:, :, :one]), 1)
             line["cpu_baseline"] = {"value": cps, "unit": "checks/s", "cores": threads, "kind": "port",
-                                    "sample": "first %d vectors of the same batch, %d threads, %.1f s" % (sample, threads, dt)}
+                                    "sample": "first %d vectors of the same batch, %d threads, %.1f s" % (sample, threads, dt),
+                                    "one_core": {"value": cps1, "sample": "first %d vectors, 1 thread, %.1f s" % (one, dt1)}}
         print(json.dumps(line), flush=True)
     ctx.release(tid)
     ctx.close()

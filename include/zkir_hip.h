@@ -178,7 +178,13 @@ typedef struct zkir_generator_config {
   uint32_t signal_window;      /* quadratic_aware: linear terms draw among the inputs
                                   and the last `signal_window` readable signals
                                   instead of all of them (0 = all)            */
-  uint32_t reserved[4];
+  uint32_t enable_if;          /* 0: never emit If, as the reference ships
+                                  (src/generator.rs:190 is commented out);
+                                  1: dispatch gen_if (src/generator.rs:355-399)
+                                  as written, conditions are random expressions;
+                                  2: the same with conditions that compare two
+                                  constants, so they are known when lowering  */
+  uint32_t reserved[3];
 } zkir_generator_config;
 
 int32_t zkir_generator_config_default(zkir_generator_config* cfg);

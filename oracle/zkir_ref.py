@@ -76,7 +76,7 @@ class Generator:
         self.loop_init_max, self.loop_bound_max, self.loop_body_max = 30, 60, 5  # :406 :416 :436
         self.name_len = 8  # :264
         self.inputs_readable = self.arithmetic_only = self.quadratic_aware = self.no_loops = 0
-        self.forced_inputs = self.safe_array_index = self.signal_window = 0
+        self.forced_inputs = self.safe_array_index = self.signal_window = self.enable_if = 0
         for k, v in cfg.items():
             assert hasattr(self, k), k
             setattr(self, k, v)
@@ -136,6 +136,8 @@ class Generator:
         has_arrays = any(v["role"] == "local" and v["array_len"] is not None for v in sv)
         has_out = any(v["role"] == "output" for v in sv)
         funcs = [lambda: self.gen_var_decl(None, None, None)]
+        if self.enable_if:  # extension: the entry the reference keeps commented out (:190)
+            funcs.append(self.gen_if)
         if not self.no_loops:
             funcs.append(self.gen_for)
         if has_vars:
@@ -207,6 +209,32 @@ class Generator:
             if e is not None:
                 return ("constrain", (vid, None), e)
         return None
+
+    def gen_if(self):  # :355-399
+        if self.enable_if == 2:  # extension: a condition lower can decide
+            k = ("lt", "eq", "gt")[self.rng.rand(0, 2)]
+            cond = (k, ("const", str(self.rng.next())), ("const", str(self.rng.next())))
+        else:
+            cond = self.generate_expr(0)
+        if cond is None:
+            return None
+        self.stack.append([])
+        then = []
+        for _ in range(self.rng.rand(1, self.loop_body_max)):
+            self._push(then, self.generate_instr())
+        self.stack.pop()
+        if not then:
+            return None
+        self.stack.append([])
+        other = None
+        if self.rng.rand(0, 1) == 0:
+            instrs = []
+            for _ in range(self.rng.rand(1, self.loop_body_max)):
+                self._push(instrs, self.generate_instr())
+            if instrs:
+                other = instrs
+        self.stack.pop()
+        return ("if", cond, then, other)
 
     def gen_for(self):  # :401-456
         self.stack.append([])

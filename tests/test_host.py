@@ -88,6 +88,16 @@ def test_generator_matches_restatement_over_seeds():
     for seed in range(1, 40):
         assert z.Generator(seed, ext_config(**cfg)).generate().text() == \
             R.print_text(R.Generator(R.Rng(seed), **cfg).generate())
+    # If statements (the reference keeps them switched off): as written, and with decidable conditions
+    n_if = 0
+    for mode in (1, 2):
+        cfg = dict(enable_if=mode, inputs_readable=1, safe_array_index=1)
+        for seed in range(1, 60):
+            text = z.Generator(seed, ext_config(**cfg)).generate().text()
+            assert text == R.print_text(R.Generator(R.Rng(seed), **cfg).generate())
+            n_if += text.count("(if ")
+            assert "(if " not in z.Generator(seed).generate().text()
+    assert n_if > 50
 
 
 def test_transpiler_tokens_one_per_operator():
@@ -248,7 +258,7 @@ def test_lower_matches_ast_interpreter_extended():
     seen = set()
     for seed in range(1, 60):
         cfg = dict(EXT, max_expr_depth=1 + seed % 3, arithmetic_only=seed % 2, quadratic_aware=(seed // 2) % 2,
-                   no_loops=(seed // 4) % 2)
+                   no_loops=(seed // 4) % 2, enable_if=(seed // 8) % 3)
         ref = R.Generator(R.Rng(seed), **cfg).generate()
         text = R.print_text(ref)
         assert z.Generator(seed, ext_config(**cfg)).generate().text() == text

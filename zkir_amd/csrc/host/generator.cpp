@@ -159,9 +159,10 @@ std::optional<Instruction> Generator::generate_instr() {
   const bool has_output_signals = scope_stack_.n_output > 0;     // any Output signal (:183-186)
 
   // candidate order of generator.rs:188-204
-  enum Cand { kVarDecl, kFor, kAssign, kArrayAssign, kConstraint };
+  enum Cand { kVarDecl, kIf, kFor, kAssign, kArrayAssign, kConstraint };
   std::vector<Cand> funcs;
   funcs.push_back(kVarDecl);
+  if (cfg_.enable_if) funcs.push_back(kIf);  // extension: the reference keeps this entry commented out (:190)
   if (!cfg_.no_loops) funcs.push_back(kFor);
   if (has_vars) funcs.push_back(kAssign);
   if (has_arrays) funcs.push_back(kArrayAssign);
@@ -170,6 +171,7 @@ std::optional<Instruction> Generator::generate_instr() {
   const size_t idx = rng_.rand(0, funcs.size() - 1);
   switch (funcs[idx]) {
     case kVarDecl: return gen_var_decl_default();
+    case kIf: return gen_if();
     case kFor: return gen_for();
     case kAssign: return gen_assign();
     case kArrayAssign: return gen_array_assign();
@@ -270,7 +272,17 @@ std::optional<Instruction> Generator::gen_constraint() {
 }
 
 std::optional<Instruction> Generator::gen_if() {
-  std::optional<Expr> cond = generate_expr(0);
+  std::optional<Expr> cond;
+  if (cfg_.enable_if == 2) {
+    // extension: a comparison of two constants, decidable when the circuit is lowered
+    static const ExprKind kCmp[] = {ExprKind::LessThan, ExprKind::Equal, ExprKind::GreaterThan};
+    const ExprKind k = kCmp[rng_.rand(0, 2)];
+    Expr l = Expr::Constant(std::to_string(rng_.next()));
+    Expr r = Expr::Constant(std::to_string(rng_.next()));
+    cond = Expr::Binary(k, std::move(l), std::move(r));
+  } else {
+    cond = generate_expr(0);
+  }
   if (!cond) return std::nullopt;
 
   scope_stack_.enter_scope();
