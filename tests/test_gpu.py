@@ -325,6 +325,85 @@ def test_device_pointer_entry_point_full_size(ctx):
     ctx.release(tid)
 
 
+def test_many_distinct_circuits_one_launch_full_width(ctx):
+    """The many-circuits configuration at its real width (1 024 vectors per circuit, circuits of
+    64 to 4 096 constraints, hundreds of tapes in one launch): nothing fails, the per-tape counts
+    of planted failures come back on the right tapes, and sampled tapes match the checker."""
+    torch = pytest.importorskip("torch")
+    from zkir_amd import campaign
+    n_circ, n_vec = 384, 1024
+    tapes = []
+    for cid in range(n_circ):
+        tapes.append(z.Lowerer(z.Generator(campaign.circuit_seed(77, cid), campaign.campaign_config(cid)).generate()).lower())
+    assert min(t.hdr.n_constraints for t in tapes) < 100 and max(t.hdr.n_constraints for t in tapes) > 3000
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    words = sum(t.hdr.n_inputs for t in tapes) * 8 * n_vec
+    inp = torch.randint(0, 1 << 32, (words,), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+    offs, off = [], 0
+    for t in tapes:
+        blk = inp[off:off + t.hdr.n_inputs * 8 * n_vec].view(t.hdr.n_inputs, 8, n_vec)
+        blk[:, 7, :] &= 0x0FFFFFFF
+        offs.append(off)
+        off += t.hdr.n_inputs * 8 * n_vec
+    # plant failures: in three tapes turn the first product into a sum
+    planted = {5: None, 200: None, 383: None}
+    for k in planted:
+        ops = tapes[k].ops()
+        j = next(i for i, op in enumerate(ops) if op[0] == F.OP_MUL)
+        ops[j] = (F.OP_ADD,) + ops[j][1:]
+        blob = b"".join(struct.pack("<4I", *op) for op in ops) + tapes[k].blob()[16 * len(ops):]
+        tapes[k] = z.Tape.from_parts(tapes[k].hdr, blob)
+    tids = [ctx.upload(t) for t in tapes]
+    unsat = torch.zeros(n_circ, dtype=torch.int64, device=dev)
+    ctx.eval_multi_dev(tids, inp.data_ptr(), n_vec, unsat.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = [int(v) for v in unsat.cpu()]
+    for k in list(planted) + [0, 100, 382]:  # the planted tapes and three clean ones, against the checker
+        t = tapes[k]
+        blk = inp[offs[k]:offs[k] + t.hdr.n_inputs * 8 * n_vec].view(t.hdr.n_inputs, 8, n_vec)
+        blk = np.ascontiguousarray(blk.cpu().numpy().view(np.uint32))
+        _, u_c, _, _ = C.eval_cpu(bytes(t.hdr), t.blob(), blk, n_vec, t.hdr.n_outputs, want_outputs=False)
+        assert got[k] == u_c, k
+    assert all(got[k] > 0 for k in planted)
+    assert all(g == 0 for k, g in enumerate(got) if k not in planted)
+    for t in tids:
+        ctx.release(t)
+
+
+def test_deep_gadget_full_size(ctx):
+    """The deep chain at its real size: 250 008 constraints over 2^16 vectors, every constraint
+    of every vector holds, and the last outputs of sampled vectors match the checker."""
+    torch = pytest.importorskip("torch")
+    tape = z.Lowerer(z.poseidon_style_gadget(4, 20834, 7)).lower()
+    h = tape.hdr
+    assert h.n_constraints == 250008
+    n = 1 << 16
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    inp = torch.randint(0, 1 << 32, (h.n_inputs, 8, n), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+    inp[:, 7, :] &= 0x0FFFFFFF
+    res = torch.zeros(4, dtype=torch.int64, device=dev)
+    tid = ctx.upload(tape)
+    ctx.eval_batch_dev(tid, inp.data_ptr(), n, None, res.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    r = res.cpu().numpy().view(np.uint64)
+    assert r[0] == 0 and r[1] == np.uint64(0xFFFFFFFFFFFFFFFF) and r[2] == 0
+    # a handful of vectors through the checker, outputs included (the chain's end depends on every round)
+    idx = torch.tensor([0, 1, 255, 256, 32767, 65535], device=dev)
+    inp_s = np.ascontiguousarray(inp[:, :, idx].cpu().numpy().view(np.uint32))
+    m = len(idx)
+    out = torch.empty((h.n_outputs, 8, m), dtype=torch.int32, device=dev)
+    inp_d = torch.from_numpy(inp_s.view(np.int32)).to(dev)
+    ctx.eval_batch_dev(tid, inp_d.data_ptr(), m, out.data_ptr(), res.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    o_c, u_c, _, _ = C.eval_cpu(bytes(h), tape.blob(), inp_s, m, h.n_outputs, threads=6)
+    assert u_c == 0 and np.array_equal(np.ascontiguousarray(out.cpu().numpy().view(np.uint32)), o_c)
+    ctx.release(tid)
+
+
 def test_measured_rates_are_sane(ctx):
     mulhi = ctx.int_mul_rate(0)
     assert 5e12 < mulhi < 6e13
