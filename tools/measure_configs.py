@@ -23,7 +23,7 @@ def main():
     dev = torch.device("cuda:0")
     ctx = z.Context(0)
     t0 = time.time()
-    tapes = [t for _, cls, t in campaign.lower_parallel(range(n_circuits), 7, processes=16) if t is not None]
+    tapes = [t for _, cls, t in campaign.lower_parallel(range(n_circuits), 7, workers=16) if t is not None]
     # longest tapes first: the work queue hands items out in order, so the tail is made of short ones
     tapes.sort(key=lambda t: -t.hdr.n_ops)
     host_s = time.time() - t0
@@ -52,7 +52,7 @@ def main():
     print(json.dumps({"config": "3: %d distinct circuits (%d lowered OK, %d..%d constraints) x %d vectors" % (
         n_circuits, len(tapes), min(t.hdr.n_constraints for t in tapes), max(t.hdr.n_constraints for t in tapes), n_vec),
         "gpu_ms": 1e3 * dt, "checks_per_s": checks / dt, "fr_mul_per_s": muls / dt, "unsat": int(unsat.sum()),
-        "host_generate_lower_s_16_procs": host_s}))
+        "host_generate_lower_s_16_threads": host_s}))
 
 
 if __name__ == "__main__":

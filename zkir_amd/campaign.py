@@ -42,30 +42,30 @@ def campaign_config(circuit_id, min_constraints=64, max_constraints=4096):
 def _lower_one(args):
     cid, base_seed = args
     try:
-        tape = api.Lowerer(api.Generator(circuit_seed(base_seed, cid), campaign_config(cid)).generate()).lower()
-        return cid, 0, bytes(tape.hdr), tape.blob()
+        return cid, 0, api.Lowerer(api.Generator(circuit_seed(base_seed, cid), campaign_config(cid)).generate()).lower()
     except api.LowerRejected as e:
-        return cid, e.status_class, None, None
+        return cid, e.status_class, None
 
 
-def lower_parallel(circuit_ids, base_seed, processes=8, pool=None):
-    """Generate and lower campaign circuits on `processes` host cores; yields
-    (circuit id, class, Tape or None) in id order.  Pass a `pool` made before the process
-    touched the GPU when the caller evaluates on one (workers are forked)."""
-    import multiprocessing as mp
-    own = pool is None
-    if own:
-        pool = mp.get_context("fork").Pool(processes)
-    try:
-        for cid, cls, hdr, blob in pool.imap(_lower_one, [(c, base_seed) for c in circuit_ids], chunksize=4):
-            if hdr is None:
-                yield cid, cls, None
-            else:
-                yield cid, cls, api.Tape.from_parts(api.TapeHdr.from_buffer_copy(hdr), blob)
-    finally:
-        if own:
-            pool.close()
-            pool.join()
+def lower_parallel(circuit_ids, base_seed, workers=8, window=64):
+    """Generate and lower campaign circuits on `workers` host threads; yields
+    (circuit id, class, Tape or None) in id order.  The library's host functions keep no
+    shared state and ctypes drops the interpreter lock around them, so plain threads scale
+    (and nothing is forked from a process that may already hold a GPU context).  At most
+    `window` x workers circuits are in flight ahead of the consumer."""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(workers) as ex:
+        pending, it = deque(), iter(circuit_ids)
+        for cid in it:
+            pending.append(ex.submit(_lower_one, (cid, base_seed)))
+            if len(pending) >= window * workers:
+                break
+        while pending:
+            yield pending.popleft().result()
+            for cid in it:
+                pending.append(ex.submit(_lower_one, (cid, base_seed)))
+                break
 
 
 class LocalResult:
@@ -209,7 +209,6 @@ def main(argv=None):
     process.  Rank 0 prints one JSON line with the job-wide totals."""
     import argparse
     import json
-    import multiprocessing as mp
     import os
     import time
 
@@ -218,12 +217,11 @@ def main(argv=None):
     ap.add_argument("--vectors", type=int, default=1024, help="input vectors per circuit")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--group", type=int, default=512, help="circuits per launch")
-    ap.add_argument("--processes", type=int, default=8, help="host processes that generate and lower, per rank")
+    ap.add_argument("--workers", type=int, default=8, help="host threads that generate and lower, per rank")
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    pool = mp.get_context("fork").Pool(args.processes)  # forked before anything touches the GPU
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
@@ -237,15 +235,13 @@ def main(argv=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     res = run_local(ids, args.seed, args.vectors, ev, group=args.group,
-                    lowered=lower_parallel(ids, args.seed, pool=pool))
+                    lowered=lower_parallel(ids, args.seed, workers=args.workers))
     tot = reduce_results(res, dist if world > 1 else None, device)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    pool.close()
-    pool.join()
     if rank == 0:
         tot.update({"n_gpus": world, "seconds": float(t.item()), "vectors_per_circuit": args.vectors,
                     "checks_per_s": tot["checks"] / float(t.item()), "circuits_per_s": tot["circuits"] / float(t.item()),

@@ -113,6 +113,18 @@ const U256& half() {
 
 bool parse_decimal(const std::string& s, U256* out) {
   if (s.empty()) return false;
+  if (s.size() <= 38) {  // below 10^38 < 2^127 < p: plain 128-bit accumulation, no reduction
+    u128 v = 0;
+    for (const char ch : s) {
+      if (ch < '0' || ch > '9') return false;
+      v = v * 10 + (u128)(ch - '0');
+    }
+    U256 r;
+    r.w[0] = (uint64_t)v;
+    r.w[1] = (uint64_t)(v >> 64);
+    *out = r;
+    return true;
+  }
   // 18 digits at a time: acc = acc * 10^k + chunk (mod p)
   U256 acc;
   size_t i = 0;

@@ -3,6 +3,8 @@
 // a seed must reproduce the same circuit here and there.
 #include "generator.hpp"
 
+#include <algorithm>
+
 #include <string>
 
 namespace zkir {
@@ -60,7 +62,13 @@ void Generator::ScopeStack::refresh(size_t pos) {
   const bool field = !v.var_type.is_array;
   ready_fields.set(pos, field && v.all_initialized());
   open_outputs.set(pos, v.role.is_output() && field && !v.all_initialized());
-  touched_arrays.set(pos, !field && v.any_initialized());
+  uint32_t written = 0;
+  for (bool b : v.initialized) written += b;
+  written_count[pos] = written;
+  const bool touched = !field && written > 0;
+  if (touched && !touched_arrays.test(pos))  // first write to this array: keep the list ascending
+    touched_list.insert(std::upper_bound(touched_list.begin(), touched_list.end(), pos), pos);
+  touched_arrays.set(pos, touched);
   ready_signals.set(pos, v.role.is_signal && field && v.all_initialized());
 }
 
@@ -82,6 +90,7 @@ Variable Generator::ScopeStack::add_var(std::string name, VariableType t, Variab
   }
   if (r.is_output()) n_output++;
   for (OrderedSet* s : {&ready_fields, &open_outputs, &touched_arrays, &ready_signals}) s->resize(pos + 1);
+  written_count.resize(pos + 1, 0);
   refresh(pos);
   return var;
 }
@@ -96,6 +105,8 @@ void Generator::ScopeStack::leave_scope() {
   while (!local_fields.empty() && local_fields.back() >= begin) local_fields.pop_back();
   while (!local_arrays.empty() && local_arrays.back() >= begin) local_arrays.pop_back();
   for (OrderedSet* s : {&ready_fields, &open_outputs, &touched_arrays, &ready_signals}) s->resize(begin);
+  while (!touched_list.empty() && touched_list.back() >= begin) touched_list.pop_back();
+  written_count.resize(begin);
   flat.resize(begin);
 }
 
@@ -130,6 +141,7 @@ Circuit Generator::generate() {
 
   const size_t n = rng_.rand(cfg_.min_instructions, cfg_.max_instructions);
   requested_ = n;
+  instructions.reserve(n + n / 2 + cfg_.forced_inputs);  // an Instruction is costly to move
 
   // extension: scalar input signals declared before anything else
   for (uint32_t k = 0; k < cfg_.forced_inputs; k++) {
@@ -393,20 +405,16 @@ std::optional<Expr> Generator::gen_array_index(size_t) {
   // One draw per array that has a written element, in scope order, then one draw to choose
   // among them (generator.rs:572-601); only the chosen array's draw is used, but every draw
   // must be made to keep the random stream aligned with the reference.
-  const size_t n = scope_stack_.touched_arrays.count();
+  const std::vector<size_t>& arrays = scope_stack_.touched_list;
+  const size_t n = arrays.size();
   size_t chosen_pos = 0, chosen_idx = 0;
   array_draws_.clear();
-  for (size_t k = 0; k < n; k++) {
-    const Variable& v = scope_stack_.flat[scope_stack_.touched_arrays.select(k)];
-    size_t written = 0;
-    for (bool b : v.initialized) written += b;
-    // a position in 0..=written, not one of the written elements (generator.rs:584): it can
-    // name an unwritten element, or one past the end when every element is written
-    array_draws_.push_back(rng_.rand(0, written));
-  }
+  // a position in 0..=written, not one of the written elements (generator.rs:584): it can
+  // name an unwritten element, or one past the end when every element is written
+  for (size_t k = 0; k < n; k++) array_draws_.push_back(rng_.rand(0, scope_stack_.written_count[arrays[k]]));
   if (n == 0) return std::nullopt;
   const size_t pick = rng_.rand(0, n - 1);
-  chosen_pos = scope_stack_.touched_arrays.select(pick);
+  chosen_pos = arrays[pick];
   chosen_idx = array_draws_[pick];
   const Variable& v = scope_stack_.flat[chosen_pos];
   if (cfg_.safe_array_index) {  // extension: always a written element

@@ -72,6 +72,8 @@ class Generator {
     OrderedSet ready_fields;     // Field and all_initialized           (gen_var_ref)
     OrderedSet open_outputs;     // Output Field not yet initialised    (gen_constraint)
     OrderedSet touched_arrays;   // Array with any element initialised  (gen_array_index)
+    std::vector<size_t> touched_list;     // the members of touched_arrays, ascending
+    std::vector<uint32_t> written_count;  // per position: elements initialised so far
     OrderedSet ready_signals;    // signal, Field, all_initialized      (extension: gen_linear)
 
     void enter_scope() { scope_begin.push_back(flat.size()); }
