@@ -34,6 +34,16 @@ struct DevTape {
   bool full = false;       // uses an operator beyond + - * : needs the full interpreter
   void* ops = nullptr;     // device
   void* consts = nullptr;  // device, Montgomery form
+  int slab = -1;           // which slab of the context's tape arena holds ops and consts
+};
+
+// Device memory for uploaded tapes: slabs with bump allocation, so that an upload costs one
+// copy and one small kernel instead of two hipMalloc calls.  A slab is reused from its start
+// once every tape in it has been released; slabs are freed with the context.
+struct TapeSlab {
+  char* base = nullptr;
+  size_t size = 0, used = 0;
+  int live = 0;  // tapes currently allocated in this slab
 };
 
 struct zkir_ctx {
@@ -56,6 +66,9 @@ struct zkir_ctx {
   void* io_unsat = nullptr;
   size_t io_unsat_bytes = 0;
   uint64_t last_faults = 0;
+  std::vector<TapeSlab> slabs;
+  hipEvent_t upload_done = nullptr;  // recorded after the latest upload's device work
+  bool upload_pending = false;       // an evaluation on another stream must wait for upload_done
 };
 
 namespace {
@@ -90,6 +103,32 @@ int32_t ensure(zkir_ctx* ctx, void** buf, size_t* have, size_t need) {
 // Grid: as many workgroups as the machine holds at once (the occupancy the kernel's
 // registers and the LDS window allow), never more than there is work; each workgroup
 // then walks the work items with a grid stride and reuses its slot region.
+// `bytes` of 256-byte-aligned device memory from the tape arena; *slab_out names the slab
+int32_t arena_alloc(zkir_ctx* ctx, size_t bytes, void** out, int* slab_out) {
+  const size_t need = (std::max<size_t>(bytes, 256) + 255) & ~(size_t)255;
+  for (size_t i = 0; i < ctx->slabs.size(); i++) {
+    TapeSlab& sl = ctx->slabs[i];
+    if (sl.live == 0) sl.used = 0;  // everything in it was released
+    if (sl.size - sl.used >= need) {
+      *out = sl.base + sl.used;
+      sl.used += need;
+      sl.live++;
+      *slab_out = (int)i;
+      return ZKIR_OK;
+    }
+  }
+  TapeSlab sl;
+  sl.size = std::max<size_t>(need, (size_t)32 << 20);
+  hipError_t e = hipMalloc((void**)&sl.base, sl.size);
+  if (e != hipSuccess) return fail(ctx, ZKIR_E_NOMEM, std::string("hipMalloc (tape arena): ") + hipGetErrorString(e));
+  sl.used = need;
+  sl.live = 1;
+  *out = sl.base;
+  ctx->slabs.push_back(sl);
+  *slab_out = (int)ctx->slabs.size() - 1;
+  return ZKIR_OK;
+}
+
 uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, int variant, uint32_t lslots) {
   int per_cu = 2;
   if (zkir::interp_blocks_per_cu(variant, lslots, &per_cu) != hipSuccess) per_cu = 2;
@@ -160,6 +199,10 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
   if (rc) return rc;
   rc = ensure(ctx, &ctx->desc_buf, &ctx->desc_buf_bytes, (size_t)n * sizeof(TapeDesc));
   if (rc) return rc;
+  if (ctx->upload_pending) {  // constants of freshly uploaded tapes are converted on the null stream
+    HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->upload_done, 0));
+    ctx->upload_pending = false;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->desc_buf, L.descs.data(), (size_t)n * sizeof(TapeDesc), hipMemcpyHostToDevice, stream));
   // L.descs is pageable host memory: hipMemcpyAsync has consumed it when it returns,
   // and the device-side staging buffer is only rewritten by later work on `stream`.
@@ -189,7 +232,10 @@ int32_t zkir_ctx_create(int32_t device, zkir_ctx** out) {
   ctx->device = device;
   ctx->n_cu = prop.multiProcessorCount;
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->result_buf, 4 * sizeof(uint64_t)) != hipSuccess ||
-      hipMalloc(&ctx->work_counter, 256) != hipSuccess) {
+      hipMalloc(&ctx->work_counter, 256) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->upload_done, hipEventDisableTiming) != hipSuccess) {
+    if (ctx->result_buf) (void)hipFree(ctx->result_buf);
+    if (ctx->work_counter) (void)hipFree(ctx->work_counter);
     delete ctx;
     return ZKIR_E_HIP;
   }
@@ -201,10 +247,8 @@ int32_t zkir_ctx_destroy(zkir_ctx* ctx) {
   if (!ctx) return ZKIR_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
-  for (auto& kv : ctx->tapes) {
-    (void)hipFree(kv.second.ops);
-    (void)hipFree(kv.second.consts);
-  }
+  for (TapeSlab& sl : ctx->slabs) (void)hipFree(sl.base);
+  if (ctx->upload_done) (void)hipEventDestroy(ctx->upload_done);
   void* bufs[] = {ctx->gslot_pool, ctx->desc_buf, ctx->result_buf, ctx->work_counter, ctx->io_in, ctx->io_out, ctx->io_unsat};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -225,24 +269,23 @@ int32_t zkir_tape_upload(zkir_ctx* ctx, const zkir_tape_hdr* hdr, const void* bl
     const uint32_t c = ((const zkir_op*)blob)[i].code;
     if (c == ZKIR_OP_BNOT || c == ZKIR_OP_BNOT256 || (c >= ZKIR_OP_POW && c <= ZKIR_OP_SHL)) t.full = true;
   }
+  // ops and constants are adjacent in the blob and stay adjacent on the device: one copy
   const size_t ops_bytes = (size_t)hdr->n_ops * sizeof(zkir_op);
   const size_t consts_bytes = (size_t)hdr->n_consts * 32;
-  if (hipMalloc(&t.ops, std::max<size_t>(ops_bytes, 16)) != hipSuccess) return fail(ctx, ZKIR_E_NOMEM, "hipMalloc ops");
-  if (hipMalloc(&t.consts, std::max<size_t>(consts_bytes, 32)) != hipSuccess) {
-    (void)hipFree(t.ops);
-    return fail(ctx, ZKIR_E_NOMEM, "hipMalloc consts");
-  }
+  void* base = nullptr;
+  int32_t rc = arena_alloc(ctx, ops_bytes + consts_bytes, &base, &t.slab);
+  if (rc) return rc;
+  t.ops = base;
+  t.consts = (char*)base + ops_bytes;
   hipError_t e = hipSuccess;
-  if (ops_bytes) e = hipMemcpy(t.ops, blob, ops_bytes, hipMemcpyHostToDevice);
-  if (e == hipSuccess && consts_bytes)
-    e = hipMemcpy(t.consts, (const char*)blob + ops_bytes, consts_bytes, hipMemcpyHostToDevice);
+  if (ops_bytes + consts_bytes) e = hipMemcpy(base, blob, ops_bytes + consts_bytes, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = zkir::launch_consts_to_mont((uint32_t*)t.consts, hdr->n_consts, nullptr);
-  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipEventRecord(ctx->upload_done, nullptr);
   if (e != hipSuccess) {
-    (void)hipFree(t.ops);
-    (void)hipFree(t.consts);
+    ctx->slabs[t.slab].live--;
     return hip_fail(ctx, e, "tape upload");
   }
+  ctx->upload_pending = true;
   *out = ctx->next_id++;
   ctx->tapes[*out] = t;
   return ZKIR_OK;
@@ -253,9 +296,8 @@ int32_t zkir_tape_release(zkir_ctx* ctx, zkir_tape_id id) {
   auto it = ctx->tapes.find(id);
   if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipDeviceSynchronize());
-  (void)hipFree(it->second.ops);
-  (void)hipFree(it->second.consts);
+  HIP_TRY(ctx, hipDeviceSynchronize());  // no launch may still be reading the tape
+  ctx->slabs[it->second.slab].live--;
   ctx->tapes.erase(it);
   return ZKIR_OK;
 }
