@@ -233,3 +233,33 @@ def test_register_discipline():
             assert G.SB <= int(m.group(1)) <= G.S_LAST, l
         for m in re.finditer(r"\bs\[(\d+):(\d+)\]", l):
             assert G.SB <= int(m.group(1)) and int(m.group(2)) <= G.S_LAST, l
+
+
+def test_zero_registers_are_written_only_in_the_prologue():
+    """The high halves of the multiplier's addend pairs are zeroed once; no later instruction may
+    name one of them as a destination (vector loads included)."""
+    import re
+    lines = [l for l in G.build() if not l.endswith(":")]
+    zeros = {int(G.Z(j)[1:]) for j in range(8)}
+    first_loop = next(i for i, l in enumerate(G.build()) if l == ".Lzk_top:")
+    n_prologue_writes = 0
+    seen_labels = 0
+    for raw in G.build():
+        if raw.endswith(":"):
+            seen_labels += raw == ".Lzk_top:"
+            continue
+        op, _, rest = raw.partition(" ")
+        if op.startswith(("s_", "buffer_store", "ds_write")):
+            continue
+        dst = rest.split(",")[0].strip()
+        regs = set()
+        m = re.fullmatch(r"v(\d+)", dst)
+        if m:
+            regs = {int(m.group(1))}
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", dst)
+        if m:
+            regs = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        if regs & zeros:
+            assert not seen_labels and op == "v_mov_b32" and rest.endswith(", 0"), raw
+            n_prologue_writes += 1
+    assert n_prologue_writes == 8 and first_loop > 0

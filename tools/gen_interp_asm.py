@@ -102,8 +102,8 @@ def mul_stream(a, x, y, r):
     are written by the last eight instructions, after every read of x and y)."""
     def mad(dst, u, v, addend):
         a.e("v_mad_u64_u32 %s, %s, %s, %s, %s" % (dst, CS, u, v, addend))
-    for j in range(8):
-        a.e("v_mov_b32 %s, 0" % Z(j))
+    # Z(0..7), the high halves of the addend pairs, are zeroed once in the prologue and never
+    # written again by any stream
     for i in range(8):
         if i == 0:
             for j in range(8):
@@ -143,8 +143,6 @@ def mul_stream(a, x, y, r):
 
 def redc_stream(a, x):
     """E(0..7) = x * 2^-256 mod p for x < p."""
-    for j in range(8):
-        a.e("v_mov_b32 %s, 0" % Z(j))
     for j in range(8):
         a.e("v_mov_b32 %s, %s" % (E(j), x[j]))
     a.e("v_mul_lo_u32 %s, %s, %s" % (M, E(0), SNP0))
@@ -279,6 +277,8 @@ def build():
         a.e("v_mov_b32 %s, 0x%08x" % (P8[j], P_LIMBS[j]))
     for j in range(8):
         a.e("v_mov_b32 %s, 0" % ACC8[j])
+    for j in range(8):
+        a.e("v_mov_b32 %s, 0" % Z(j))
     a.e("v_mov_b32 %s, -1" % FIRST)
     a.e("s_mov_b64 %s, 0" % UNSAT)
     a.e("s_mov_b32 %s, 0" % KCHK)
