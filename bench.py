@@ -27,9 +27,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, datasheet
 MULHI_PEAK_THEORETICAL = 256 * 4 * 16 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock: one v_mul_hi_u32 per lane per clock
 
 
-def workload_tape(z, signal_window=0):
+def workload_tape(z, signal_window=0, linear_terms=1):
+    """configs[1] of BASELINE.json: about 1k rank-1 constraints `out <== lin*lin + lin`, about 1k
+    products and about 2k additions/subtractions over 16 inputs.  linear_terms=1 (each `lin` is one
+    signal or constant) gives that mix; 2 gives sums of two, i.e. twice the additions and more
+    witness-slot traffic."""
     g = z.default_generator_config()
     g.signal_window = signal_window
+    g.max_linear_terms = linear_terms
     g.min_instructions = g.max_instructions = 4200
     g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = 16, 1, 1, 1
     g.no_loops, g.safe_array_index = 1, 1
@@ -84,6 +89,9 @@ def main():
     ap.add_argument("--signal-window", type=int, default=0,
                     help="config2 only: linear terms read the inputs and the last W signals instead of any "
                          "earlier signal (0 = any, the default line)")
+    ap.add_argument("--linear-terms", type=int, default=1, choices=[1, 2],
+                    help="config2 only: terms per linear part of a constraint (1: the default line; 2: the "
+                         "addition-heavy variant)")
     args = ap.parse_args()
 
     import numpy as np
@@ -103,7 +111,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     gadget = args.workload == "gadget"
-    tape = gadget_tape(z, args.gadget_rounds) if gadget else workload_tape(z, args.signal_window)
+    tape = gadget_tape(z, args.gadget_rounds) if gadget else workload_tape(z, args.signal_window, args.linear_terms)
     h = tape.hdr
     if gadget and args.log2_vectors == LOG2_VECTORS:
         args.log2_vectors = 16
@@ -169,7 +177,8 @@ def main():
                 and not os.environ.get("ZKIR_INTERP")):
             try:
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                    traffic = json.load(f)["config2_seed%d_2^%d_window4" % (WORKLOAD_SEED, LOG2_VECTORS)]["bytes_per_launch"]
+                    key = "config2_seed%d_2^%d_window4_terms%d" % (WORKLOAD_SEED, LOG2_VECTORS, args.linear_terms)
+                    traffic = json.load(f)[key]["bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 traffic = None
         line = {
@@ -189,8 +198,11 @@ def main():
                 "workload": ("Poseidon-style gadget chain (width 4, %d rounds) x 2^%d vectors per GPU; witness + checks, "
                              "outputs not requested" % (args.gadget_rounds, args.log2_vectors)) if gadget else
                             ("one generated circuit (extended generator, seed %d%s) x 2^%d uniform input vectors per GPU; "
-                             "witness + outputs + checks" % (WORKLOAD_SEED, ", signal window %d" % args.signal_window
-                                                             if args.signal_window else "", args.log2_vectors)),
+                             "witness + outputs + checks" % (
+                                 WORKLOAD_SEED,
+                                 (", %d-term linear parts" % args.linear_terms) +
+                                 (", signal window %d" % args.signal_window if args.signal_window else ""),
+                                 args.log2_vectors)),
                 "n_constraints": h.n_constraints, "n_mul_ops": h.n_mul_ops, "n_ops": h.n_ops,
                 "n_inputs": h.n_inputs, "n_outputs": h.n_outputs, "vectors_per_gpu": n,
                 "device_slots": h.n_gslots, "window_slots": h.n_lslots,
@@ -219,7 +231,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
-            sample = (64 if gadget else 8192) * threads  # a few seconds of work per thread
+            sample = min(n, (512 if gadget else 65536) * threads)  # about ten seconds of work per thread
             inp_s = np.ascontiguousarray(inp[:, :, :sample].cpu().numpy().view(np.uint32))
             cps, dt = cpu_baseline(tape, inp_s, threads)
             one = max(1, sample // threads)

@@ -184,7 +184,10 @@ typedef struct zkir_generator_config {
                                   as written, conditions are random expressions;
                                   2: the same with conditions that compare two
                                   constants, so they are known when lowering  */
-  uint32_t reserved[3];
+  uint32_t max_linear_terms;   /* quadratic_aware: each of the three linear parts of
+                                  `lin*lin+lin` has up to this many terms (1 or 2;
+                                  0 means 2)                                    */
+  uint32_t reserved[2];
 } zkir_generator_config;
 
 int32_t zkir_generator_config_default(zkir_generator_config* cfg);

@@ -76,7 +76,7 @@ class Generator:
         self.loop_init_max, self.loop_bound_max, self.loop_body_max = 30, 60, 5  # :406 :416 :436
         self.name_len = 8  # :264
         self.inputs_readable = self.arithmetic_only = self.quadratic_aware = self.no_loops = 0
-        self.forced_inputs = self.safe_array_index = self.signal_window = self.enable_if = 0
+        self.forced_inputs = self.safe_array_index = self.signal_window = self.enable_if = self.max_linear_terms = 0
         for k, v in cfg.items():
             assert hasattr(self, k), k
             setattr(self, k, v)
@@ -312,6 +312,8 @@ class Generator:
             return ("const", str(self.rng.next()))
 
         t = term()
+        if self.max_linear_terms == 1:
+            return t
         shape = self.rng.rand(0, 2)
         if shape == 0:
             return t

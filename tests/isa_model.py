@@ -298,6 +298,8 @@ class Lane:
             else:
                 r = (x * y) >> 32
             self.swrite(a[0], r)
+        elif op == "s_cselect_b32":
+            self.swrite(a[0], self.sread(a[1]) if self.scc else self.sread(a[2]))
         elif op == "s_and_b64":
             r = self.sread64(a[1]) & self.sread64(a[2])
             self.swrite64(a[0], r)

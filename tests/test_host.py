@@ -84,6 +84,10 @@ def test_generator_matches_restatement_over_seeds():
     for seed in range(1, 12):
         assert z.Generator(seed, ext_config(**cfg)).generate().text() == \
             R.print_text(R.Generator(R.Rng(seed), **cfg).generate())
+    cfg = dict(cfg, max_linear_terms=1, signal_window=0)
+    for seed in range(1, 8):
+        assert z.Generator(seed, ext_config(**cfg)).generate().text() == \
+            R.print_text(R.Generator(R.Rng(seed), **cfg).generate())
     cfg = dict(min_instructions=40, max_instructions=80, max_expr_depth=3, inputs_readable=1, safe_array_index=1)
     for seed in range(1, 40):
         assert z.Generator(seed, ext_config(**cfg)).generate().text() == \

@@ -263,3 +263,48 @@ def test_zero_registers_are_written_only_in_the_prologue():
             assert not seen_labels and op == "v_mov_b32" and rest.endswith(", 0"), raw
             n_prologue_writes += 1
     assert n_prologue_writes == 8 and first_loop > 0
+
+
+def test_operand_registers_are_reused_and_invalidated():
+    """An operand whose value already sits in the a or b registers is not loaded again; a store
+    to its slot, or anything else that overwrites those registers, forces the reload."""
+    rnd = random.Random(12)
+    NONE, ACC = O(F.K_NONE), O(F.K_ACC)
+    G0, G1, G2, L0 = O(F.K_GSLOT, 0), O(F.K_GSLOT, 1), O(F.K_GSLOT, 2), O(F.K_LSLOT, 0)
+    head = [(F.OP_INPUT, G0, O(F.K_INPUT, 0), NONE), (F.OP_INPUT, G1, O(F.K_INPUT, 1), NONE),
+            (F.OP_INPUT, G2, O(F.K_INPUT, 2), NONE)]
+    reuse = head + [
+        (F.OP_MUL, L0, G0, G1),          # loads G0, G1
+        (F.OP_ADD, NONE, ACC, G2),       # loads G2 into the b registers
+        (F.OP_OUTPUT, 0, ACC, NONE),
+        (F.OP_SUB, NONE, ACC, G2),       # b is still there
+        (F.OP_CHECK, ACC, G0, G1),       # a is still there, b is reloaded
+        (F.OP_CHECK, L0, G0, G1),        # a was overwritten by the product, b still there; c (L0) replaces b
+        (F.OP_MUL, NONE, O(F.K_CONST, 0), L0),  # L0 sits in the b registers
+        (F.OP_OUTPUT, 1, ACC, NONE),
+    ]
+    inputs = [[rnd.randrange(F.P) for _ in range(3)] for _ in range(2)]
+    consts = [rnd.randrange(F.P)]
+    want_out, want_unsat = oracle(reuse, consts, inputs[1], 2)
+    got_out, unsat, first, ln = run_lane(reuse, consts, inputs, 2, 1, 3, 1, lane=3)
+    assert got_out == want_out and unsat == len(want_unsat) == 0
+    # device-slot loads: G0, G1, G2, then G1 (first CHECK), G0 (second CHECK) = 5 values = 10 instructions
+    assert ln.counts["buffer_load_dwordx4"] == 10
+    assert ln.counts["ds_read_b128"] == 2  # L0 once, as c of the second CHECK
+
+    stale = head + [
+        (F.OP_MUL, NONE, G0, G1),
+        (F.OP_ADD, G0, ACC, G2),         # overwrites G0 while its old value sits in the a registers
+        (F.OP_MUL, G1, G0, G1),          # must see the new G0; then overwrites G1 (in the b registers)
+        (F.OP_SUB, L0, G0, G1),          # must see the new G1
+        (F.OP_OUTPUT, 0, ACC, NONE),
+        (F.OP_ADD, L0, L0, L0),          # reads L0 twice, then overwrites it
+        (F.OP_SUB, NONE, L0, G2),        # must see the new L0
+        (F.OP_OUTPUT, 1, ACC, NONE),
+        (F.OP_NEG, NONE, G2, NONE),      # zeroes the a registers behind the tag's back
+        (F.OP_ADD, NONE, L0, G2),        # a must be reloaded
+        (F.OP_OUTPUT, 2, ACC, NONE),
+    ]
+    want_out, _ = oracle(stale, [], inputs[0], 3)
+    got_out, _, _, _ = run_lane(stale, [], inputs, 3, 1, 3, 0, wave=1, lane=40)
+    assert got_out == want_out

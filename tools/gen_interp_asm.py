@@ -64,6 +64,7 @@ CS = "s[%d:%d]" % (SB + 30, SB + 31)   # carry-out of the multiply-adds (never r
 CC2 = "s[%d:%d]" % (SB + 32, SB + 33)  # a saved borrow / the failing lanes of a check
 T0, T1, T2, T3 = ["s%d" % (SB + 34 + k) for k in range(4)]
 SNP0, AACC, VMF, N32 = "s%d" % (SB + 38), "s%d" % (SB + 39), "s%d" % (SB + 40), "s%d" % (SB + 41)
+TAG_A, TAG_B = "s%d" % (SB + 42), "s%d" % (SB + 43)  # operand words whose values sit in the a / b registers
 CST8 = "s[%d:%d]" % (SB + 44, SB + 51)
 cst_word = lambda j: "s%d" % (SB + 44 + j)
 S_LAST = SB + 51
@@ -198,12 +199,18 @@ def sub_stream(a, x, y, r):
 
 
 # ---- operand access ----------------------------------------------------------
-def fetch(a, sop, dst_base, addr, acc_label=None, stem="f"):
+def fetch(a, sop, dst_base, addr, acc_label=None, stem="f", tag=None):
     """Issue the loads of the operand word in SGPR `sop` into v[dst_base..+7].
     kind ACC: jump to acc_label if given (nothing loaded), else copy the accumulator.
-    Device-slot loads set VMF so the caller knows to wait on vmcnt."""
+    Device-slot loads set VMF so the caller knows to wait on vmcnt.
+    tag: the SGPR that remembers which operand word these registers hold; when it equals
+    `sop` the value is already there (no op stored to that slot since: stores reset the tag)
+    and nothing is loaded."""
     dst = vreg8(dst_base)
     l_lds, l_glb, l_cst, l_done = a.new(stem + "lds"), a.new(stem + "glb"), a.new(stem + "cst"), a.new(stem + "done")
+    if tag:
+        a.e("s_cmp_eq_u32 %s, %s" % (sop, tag))
+        a.e("s_cbranch_scc1 %s" % l_done)
     a.e("s_lshr_b32 %s, %s, 29" % (T0, sop))
     a.e("s_and_b32 %s, %s, 0x1fffffff" % (T1, sop))
     a.e("s_cmp_eq_u32 %s, %d" % (T0, K_LSLOT))
@@ -221,14 +228,20 @@ def fetch(a, sop, dst_base, addr, acc_label=None, stem="f"):
     # any other kind reads as zero (the host validates tapes; this keeps the stream total)
     for j in range(8):
         a.e("v_mov_b32 %s, 0" % dst[j])
+    if tag:
+        a.e("s_mov_b32 %s, -1" % tag)
     a.e("s_branch %s" % l_done)
     if not acc_label:
         a.label(l_acc)
         if dst_base != VACC:
             for j in range(8):
                 a.e("v_mov_b32 %s, %s" % (dst[j], ACC8[j]))
+            if tag:
+                a.e("s_mov_b32 %s, -1" % tag)
         a.e("s_branch %s" % l_done)
     a.label(l_cst)
+    if tag:
+        a.e("s_mov_b32 %s, %s" % (tag, sop))
     a.e("s_lshl_b32 %s, %s, 5" % (T1, T1))
     a.e("s_buffer_load_dwordx8 %s, %s, %s" % (CST8, D_CST, T1))
     a.e("s_waitcnt lgkmcnt(0)")
@@ -236,6 +249,8 @@ def fetch(a, sop, dst_base, addr, acc_label=None, stem="f"):
         a.e("v_mov_b32 %s, %s" % (dst[j], cst_word(j)))
     a.e("s_branch %s" % l_done)
     a.label(l_glb)
+    if tag:
+        a.e("s_mov_b32 %s, %s" % (tag, sop))
     a.e("s_lshl_b32 %s, %s, 13" % (T1, T1))
     a.e("v_add_u32 %s, %s, %s" % (addr, T1, IN_VLO))
     a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen" % (quad(dst_base, 0), addr, D_GS))
@@ -243,6 +258,8 @@ def fetch(a, sop, dst_base, addr, acc_label=None, stem="f"):
     a.e("s_mov_b32 %s, 1" % VMF)
     a.e("s_branch %s" % l_done)
     a.label(l_lds)
+    if tag:
+        a.e("s_mov_b32 %s, %s" % (tag, sop))
     a.e("s_lshl_b32 %s, %s, 13" % (T1, T1))
     a.e("s_add_u32 %s, %s, %s" % (T1, T1, IN_LDSB))
     a.e("v_add_u32 %s, %s, %s" % (addr, T1, IN_VLO))
@@ -280,6 +297,8 @@ def build():
     for j in range(8):
         a.e("v_mov_b32 %s, 0" % Z(j))
     a.e("v_mov_b32 %s, -1" % FIRST)
+    a.e("s_mov_b32 %s, -1" % TAG_A)
+    a.e("s_mov_b32 %s, -1" % TAG_B)
     a.e("s_mov_b64 %s, 0" % UNSAT)
     a.e("s_mov_b32 %s, 0" % KCHK)
     a.e("s_mov_b32 %s, 0x%08x" % (SNP0, NP0))
@@ -307,9 +326,9 @@ def build():
     a.e("s_cbranch_scc1 .Lzk_unary")
 
     # binary ops and CHECK: fetch b, then a (or note that a is the accumulator)
-    fetch(a, OP[3], VBB, AD_B, stem="b")
+    fetch(a, OP[3], VBB, AD_B, stem="b", tag=TAG_B)
     a.e("s_mov_b32 %s, 0" % AACC)
-    fetch(a, OP[2], VA, AD_A, acc_label=".Lzk_a_is_acc", stem="a")
+    fetch(a, OP[2], VA, AD_A, acc_label=".Lzk_a_is_acc", stem="a", tag=TAG_A)
     a.e("s_branch .Lzk_have_ab")
     a.label(".Lzk_a_is_acc")
     a.e("s_mov_b32 %s, 1" % AACC)
@@ -363,8 +382,9 @@ def build():
     a.label(".Lzk_check_acc")
     mul_stream(a, ACC8, B8, A8)
     a.label(".Lzk_check_cmp")
+    a.e("s_mov_b32 %s, -1" % TAG_A)  # the a registers now hold the product
     a.e("s_mov_b32 %s, 0" % VMF)
-    fetch(a, OP[1], VBB, AD_C, acc_label=".Lzk_cmp_acc", stem="c")
+    fetch(a, OP[1], VBB, AD_C, acc_label=".Lzk_cmp_acc", stem="c", tag=TAG_B)
     wait_loads(a)
 
     def compare(c):
@@ -435,13 +455,15 @@ def build():
         a.e("buffer_load_dword %s, %s, %s, %s offen" % (A8[j], IN_VVEC, D_IO, cst_word(j)))
     for j in range(8):
         a.e("v_mov_b32 %s, 0x%08x" % (B8[j], R2_LIMBS[j]))
+    a.e("s_mov_b32 %s, -1" % TAG_A)
+    a.e("s_mov_b32 %s, -1" % TAG_B)
     a.e("s_waitcnt vmcnt(0)")
     a.e("s_branch .Lzk_mul_ab")
 
     a.label(".Lzk_output")
     a.e("s_cmp_eq_u64 %s, 0" % IN_OUTB)  # nobody wants the outputs: skip the conversion too
     a.e("s_cbranch_scc1 .Lzk_next")
-    fetch(a, OP[2], VA, AD_A, acc_label=".Lzk_out_acc", stem="o")
+    fetch(a, OP[2], VA, AD_A, acc_label=".Lzk_out_acc", stem="o", tag=TAG_A)
     wait_loads(a)
     redc_stream(a, A8)
     a.e("s_branch .Lzk_out_store")
@@ -462,7 +484,8 @@ def build():
     a.e("s_branch .Lzk_store")
 
     a.label(".Lzk_neg")  # 0 - a
-    fetch(a, OP[2], VBB, AD_B, stem="n")
+    fetch(a, OP[2], VBB, AD_B, stem="n", tag=TAG_B)
+    a.e("s_mov_b32 %s, -1" % TAG_A)
     for j in range(8):
         a.e("v_mov_b32 %s, 0" % A8[j])
     wait_loads(a)
@@ -470,6 +493,11 @@ def build():
 
     # ---- store the accumulator where the op says ---------------------------
     a.label(".Lzk_store")
+    # a value remembered in the operand registers dies when its slot is overwritten
+    a.e("s_cmp_eq_u32 %s, %s" % (OP[1], TAG_A))
+    a.e("s_cselect_b32 %s, -1, %s" % (TAG_A, TAG_A))
+    a.e("s_cmp_eq_u32 %s, %s" % (OP[1], TAG_B))
+    a.e("s_cselect_b32 %s, -1, %s" % (TAG_B, TAG_B))
     a.e("s_lshr_b32 %s, %s, 29" % (T0, OP[1]))
     a.e("s_and_b32 %s, %s, 0x1fffffff" % (T1, OP[1]))
     a.e("s_lshl_b32 %s, %s, 13" % (T1, T1))

@@ -44,7 +44,7 @@ class GeneratorConfig(ctypes.Structure):
     _fields_ = [(n, c_uint32) for n in ("min_instructions", "max_instructions", "statement_budget", "max_array_len",
                                         "max_expr_depth", "loop_init_max", "loop_bound_max", "loop_body_max",
                                         "name_len", "inputs_readable", "arithmetic_only", "quadratic_aware",
-                                        "forced_inputs", "no_loops", "safe_array_index", "signal_window", "enable_if")] + [("reserved", c_uint32 * 3)]
+                                        "forced_inputs", "no_loops", "safe_array_index", "signal_window", "enable_if", "max_linear_terms")] + [("reserved", c_uint32 * 2)]
 
 
 class LowerOptions(ctypes.Structure):

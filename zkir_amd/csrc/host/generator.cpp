@@ -451,6 +451,7 @@ Expr Generator::gen_linear() {
     return Expr::Constant(std::to_string(rng_.next()));
   };
   Expr t = term();
+  if (cfg_.max_linear_terms == 1) return t;
   const uint64_t shape = rng_.rand(0, 2);
   if (shape == 0) return t;
   return Expr::Binary(shape == 1 ? ExprKind::Add : ExprKind::Sub, std::move(t), term());
