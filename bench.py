@@ -173,8 +173,8 @@ def main():
         # HBM bytes per launch from the counter passes committed under profiles/ (only for the
         # exact workload they were taken on; counters cannot be read from inside this process)
         traffic = None
-        if (not gadget and args.signal_window == 0 and args.log2_vectors == LOG2_VECTORS and h.n_lslots == 4
-                and not os.environ.get("ZKIR_INTERP")):
+        if (not gadget and args.signal_window == 0 and args.log2_vectors == LOG2_VECTORS
+                and not any(k.startswith("ZKIR_") for k in os.environ)):
             try:
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                     key = "config2_seed%d_2^%d_window4_terms%d" % (WORKLOAD_SEED, LOG2_VECTORS, args.linear_terms)
@@ -231,10 +231,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
-            sample = min(n, (512 if gadget else 65536) * threads)  # about ten seconds of work per thread
+            sample = min(n, (64 if gadget else 8192) * threads)  # about 20 core-seconds of work in all
             inp_s = np.ascontiguousarray(inp[:, :, :sample].cpu().numpy().view(np.uint32))
             cps, dt = cpu_baseline(tape, inp_s, threads)
-            one = max(1, sample // threads)
+            one = max(1, sample // 4)
             cps1, dt1 = cpu_baseline(tape, np.ascontiguousarray(inp_s[:, :, :one]), 1)
             line["cpu_baseline"] = {"value": cps, "unit": "checks/s", "cores": threads, "kind": "port",
                                     "sample": "first %d vectors of the same batch, %d threads, %.1f s" % (sample, threads, dt),
