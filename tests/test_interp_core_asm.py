@@ -30,7 +30,7 @@ IN_BASE, OUT_BASE, LDS_BASE = 0x7E0000000400, 0x7D0000000800, 16
 
 
 def run_lane(ops, consts, inputs, n_outputs, n_lslots, n_gslots, vec, wave=0, lane=0, live=True, want_outputs=True,
-             block=3):
+             block=3, victim=True):
     """inputs: list over vectors of lists of ints.  Returns (outputs list or None, unsat, first, Lane)."""
     n_vec = len(inputs)
     n_inputs = len(inputs[0]) if inputs else 0
@@ -57,12 +57,14 @@ def run_lane(ops, consts, inputs, n_outputs, n_lslots, n_gslots, vec, wave=0, la
     bit = 1 << lane
     operands = {
         "%[ops]": OPS_BASE, "%[n_ops]": len(ops), "%[consts]": CST_BASE, "%[n_consts]": len(consts),
-        "%[gslots]": gs, "%[gslot_bytes]": gs_bytes, "%[lds_base]": LDS_BASE,
+        "%[gslots]": gs, "%[gslot_bytes]": gs_bytes,
+        "%[lds_base]": LDS_BASE + (8192 if victim else 0),  # the victim row, if any, comes first
+        "%[evict_below]": 0x20000000 if victim else 0,
         "%[in_base]": IN_BASE, "%[out_base]": OUT_BASE if want_outputs else 0,
         "%[n4]": 4 * n_vec, "%[live]": (0x8000000000000001 | bit) if live else (0x8000000000000001 & ~bit),
         "%[v_lo]": wave * 2048 + lane * 16, "%[v_vec4]": 4 * v,
     }
-    ln = IM.Lane(mem, LDS_BASE + n_lslots * 8192, lane, operands, set(range(G.VB, G.V_LAST + 1)),
+    ln = IM.Lane(mem, LDS_BASE + (n_lslots + (1 if victim else 0)) * 8192, lane, operands, set(range(G.VB, G.V_LAST + 1)),
                  set(range(G.SB, G.S_LAST + 1)), result_operands=("%[unsat]", "%[first]"))
     ln.run(PROG, LABELS)
     outs = None
@@ -288,9 +290,14 @@ def test_operand_registers_are_reused_and_invalidated():
     want_out, want_unsat = oracle(reuse, consts, inputs[1], 2)
     got_out, unsat, first, ln = run_lane(reuse, consts, inputs, 2, 1, 3, 1, lane=3)
     assert got_out == want_out and unsat == len(want_unsat) == 0
-    # device-slot loads: G0, G1, G2, then G1 (first CHECK), G0 (second CHECK) = 5 values = 10 instructions
-    assert ln.counts["buffer_load_dwordx4"] == 10
-    assert ln.counts["ds_read_b128"] == 2  # L0 once, as c of the second CHECK
+    # device-slot loads: G0, G1, G2, then G0 again for the second CHECK = 4 values = 8 instructions;
+    # G1 for the first CHECK comes back from the victim row, where G2's arrival had pushed it
+    assert ln.counts["buffer_load_dwordx4"] == 8
+    assert ln.counts["ds_read_b128"] == 4  # G1 from the victim row, L0 as c of the second CHECK
+    # without a victim row (launches with a large window) G1 is loaded again, and LDS holds the window only
+    got_out, unsat, first, ln = run_lane(reuse, consts, inputs, 2, 1, 3, 1, lane=3, victim=False)
+    assert got_out == want_out and unsat == 0
+    assert ln.counts["buffer_load_dwordx4"] == 10 and ln.counts["ds_read_b128"] == 2 and "ds_write_b128" in ln.counts
 
     stale = head + [
         (F.OP_MUL, NONE, G0, G1),
@@ -306,5 +313,6 @@ def test_operand_registers_are_reused_and_invalidated():
         (F.OP_OUTPUT, 2, ACC, NONE),
     ]
     want_out, _ = oracle(stale, [], inputs[0], 3)
-    got_out, _, _, _ = run_lane(stale, [], inputs, 3, 1, 3, 0, wave=1, lane=40)
-    assert got_out == want_out
+    for victim in (True, False):
+        got_out, _, _, _ = run_lane(stale, [], inputs, 3, 1, 3, 0, wave=1, lane=40, victim=victim)
+        assert got_out == want_out

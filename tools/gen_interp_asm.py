@@ -3,7 +3,7 @@
 one tape for one wavefront (64 input vectors), for tapes made of + - * and data movement.
 
 The stream is one asm statement inside zkir_interp_lean_kernel.  Its contract with the C++
-around it: every operand of the statement is read-only until the last three instructions
+around it: every operand of the statement is read-only until the last two instructions
 (which write the two results), every register the stream writes is a physical register
 named in the clobber list, every memory access goes through a buffer descriptor with a
 byte count (the hardware drops accesses beyond it) or to LDS.
@@ -12,6 +12,13 @@ Per op: the 16-byte op arrives by scalar load one op ahead; operands are fetched
 (LDS window / device slot / constant pool / accumulator); + - * run on fixed registers,
 the product with the Montgomery stream of gen_fr_mul_asm.py; the result stays in the
 accumulator registers and is stored if the op names a destination.
+
+Operand registers carry tags: the a and b registers remember which operand word they hold, so
+an op that reads what the previous ops already fetched loads nothing; a device-slot value pushed
+out of them is parked in one victim row of LDS (the 8 KiB below the window; `lds_base` is the
+window's start) and read back from there if it is the next thing wanted (launches whose LDS
+window is large run without the row: `evict_below` = 0 switches the parking off).  A store to a slot
+clears every tag that names it.
 
 Slot layout (both LDS window and device slots): slot s occupies 8 KiB;
   byte(s, wave, plane, lane) = s*8192 + wave*2048 + plane*1024 + lane*16
@@ -63,11 +70,13 @@ KCHK, CODE = "s%d" % (SB + 28), "s%d" % (SB + 29)
 CS = "s[%d:%d]" % (SB + 30, SB + 31)   # carry-out of the multiply-adds (never read)
 CC2 = "s[%d:%d]" % (SB + 32, SB + 33)  # a saved borrow / the failing lanes of a check
 T0, T1, T2, T3 = ["s%d" % (SB + 34 + k) for k in range(4)]
-SNP0, AACC, VMF, N32 = "s%d" % (SB + 38), "s%d" % (SB + 39), "s%d" % (SB + 40), "s%d" % (SB + 41)
+SNP0, AACC, VMF = "s%d" % (SB + 38), "s%d" % (SB + 39), "s%d" % (SB + 40)
 TAG_A, TAG_B = "s%d" % (SB + 42), "s%d" % (SB + 43)  # operand words whose values sit in the a / b registers
 CST8 = "s[%d:%d]" % (SB + 44, SB + 51)
 cst_word = lambda j: "s%d" % (SB + 44 + j)
+TAG_V = "s%d" % (SB + 41)  # device-slot operand word whose value sits in the victim row of LDS
 S_LAST = SB + 51
+assert S_LAST <= 99  # s100 and above are reserved by the compiler on this target
 
 K_GSLOT, K_LSLOT, K_CONST, K_INPUT, K_ACC, K_NONE = 0, 1, 2, 3, 4, 5
 OP_INPUT, OP_OUTPUT, OP_COPY, OP_NEG, OP_ADD, OP_SUB, OP_MUL, OP_CHECK = 1, 2, 3, 4, 16, 17, 18, 48
@@ -78,6 +87,7 @@ IN_GS, IN_GSBYTES, IN_LDSB = "%[gslots]", "%[gslot_bytes]", "%[lds_base]"
 IN_INB, IN_OUTB = "%[in_base]", "%[out_base]"
 IN_N4, IN_LIVE = "%[n4]", "%[live]"
 IN_VLO, IN_VVEC = "%[v_lo]", "%[v_vec4]"
+IN_EVICT = "%[evict_below]"  # 0x20000000 when the launch has a victim row, 0 when it has none
 OUT_UNSAT, OUT_FIRST = "%[unsat]", "%[first]"
 
 
@@ -208,19 +218,34 @@ def fetch(a, sop, dst_base, addr, acc_label=None, stem="f", tag=None):
     and nothing is loaded."""
     dst = vreg8(dst_base)
     l_lds, l_glb, l_cst, l_done = a.new(stem + "lds"), a.new(stem + "glb"), a.new(stem + "cst"), a.new(stem + "done")
+    l_vhit, l_noev = a.new(stem + "vhit"), a.new(stem + "noev")
     if tag:
         a.e("s_cmp_eq_u32 %s, %s" % (sop, tag))
         a.e("s_cbranch_scc1 %s" % l_done)
+        a.e("s_cmp_eq_u32 %s, %s" % (sop, TAG_V))  # TAG_V only ever holds device-slot words
+        a.e("s_cbranch_scc1 %s" % l_vhit)
     a.e("s_lshr_b32 %s, %s, 29" % (T0, sop))
     a.e("s_and_b32 %s, %s, 0x1fffffff" % (T1, sop))
-    a.e("s_cmp_eq_u32 %s, %d" % (T0, K_LSLOT))
-    a.e("s_cbranch_scc1 %s" % l_lds)
     a.e("s_cmp_eq_u32 %s, %d" % (T0, K_ACC))
     if acc_label:
         a.e("s_cbranch_scc1 %s" % acc_label)
     else:
         l_acc = a.new(stem + "acc")
         a.e("s_cbranch_scc1 %s" % l_acc)
+    if tag:
+        # The registers are about to be overwritten.  If they hold a device-slot value, park it
+        # in this wave's victim row of LDS (the 8 KiB below the window): the next read of that
+        # slot then comes from LDS instead of device memory.
+        a.e("s_cmp_lt_u32 %s, %s" % (tag, IN_EVICT))  # kind GSLOT is 0: its words are below 2^29
+        a.e("s_cbranch_scc0 %s" % l_noev)
+        a.e("s_sub_u32 %s, %s, 8192" % (T2, IN_LDSB))
+        a.e("v_add_u32 %s, %s, %s" % (VT1, T2, IN_VLO))
+        a.e("ds_write_b128 %s, %s" % (VT1, quad(dst_base, 0)))
+        a.e("ds_write_b128 %s, %s offset:1024" % (VT1, quad(dst_base, 1)))
+        a.e("s_mov_b32 %s, %s" % (TAG_V, tag))
+        a.label(l_noev)
+    a.e("s_cmp_eq_u32 %s, %d" % (T0, K_LSLOT))
+    a.e("s_cbranch_scc1 %s" % l_lds)
     a.e("s_cmp_eq_u32 %s, %d" % (T0, K_GSLOT))
     a.e("s_cbranch_scc1 %s" % l_glb)
     a.e("s_cmp_eq_u32 %s, %d" % (T0, K_CONST))
@@ -265,6 +290,14 @@ def fetch(a, sop, dst_base, addr, acc_label=None, stem="f", tag=None):
     a.e("v_add_u32 %s, %s, %s" % (addr, T1, IN_VLO))
     a.e("ds_read_b128 %s, %s" % (quad(dst_base, 0), addr))
     a.e("ds_read_b128 %s, %s offset:1024" % (quad(dst_base, 1), addr))
+    if tag:
+        a.e("s_branch %s" % l_done)
+        a.label(l_vhit)  # the value waits in the victim row (what the registers held is dropped)
+        a.e("s_mov_b32 %s, %s" % (tag, sop))
+        a.e("s_sub_u32 %s, %s, 8192" % (T2, IN_LDSB))
+        a.e("v_add_u32 %s, %s, %s" % (addr, T2, IN_VLO))
+        a.e("ds_read_b128 %s, %s" % (quad(dst_base, 0), addr))
+        a.e("ds_read_b128 %s, %s offset:1024" % (quad(dst_base, 1), addr))
     a.label(l_done)
 
 
@@ -299,10 +332,10 @@ def build():
     a.e("v_mov_b32 %s, -1" % FIRST)
     a.e("s_mov_b32 %s, -1" % TAG_A)
     a.e("s_mov_b32 %s, -1" % TAG_B)
+    a.e("s_mov_b32 %s, -1" % TAG_V)
     a.e("s_mov_b64 %s, 0" % UNSAT)
     a.e("s_mov_b32 %s, 0" % KCHK)
     a.e("s_mov_b32 %s, 0x%08x" % (SNP0, NP0))
-    a.e("s_lshl_b32 %s, %s, 3" % (N32, IN_N4))
     a.e("s_mov_b32 %s, %s" % (REM, IN_NOPS))
     a.e("s_cmp_eq_u32 %s, 0" % REM)
     a.e("s_cbranch_scc1 .Lzk_end")
@@ -431,13 +464,13 @@ def build():
 
     def io_descriptor(base, index_reg):
         # element `index` of the tape's inputs (outputs): 8 limb rows of n vectors, 32*n bytes
-        a.e("s_mul_i32 %s, %s, %s" % (T2, index_reg, N32))
-        a.e("s_mul_hi_u32 %s, %s, %s" % (T3, index_reg, N32))
+        a.e("s_lshl_b32 %s, %s, 3" % (d_word(3, 2), IN_N4))  # 32*n bytes: the descriptor's byte count
+        a.e("s_mul_i32 %s, %s, %s" % (T2, index_reg, d_word(3, 2)))
+        a.e("s_mul_hi_u32 %s, %s, %s" % (T3, index_reg, d_word(3, 2)))
         a.e("s_mov_b64 s[%d:%d], %s" % (SB + 12, SB + 13, base))
         a.e("s_add_u32 %s, %s, %s" % (d_word(3, 0), d_word(3, 0), T2))
         a.e("s_addc_u32 %s, %s, %s" % (d_word(3, 1), d_word(3, 1), T3))
         a.e("s_and_b32 %s, %s, 0xffff" % (d_word(3, 1), d_word(3, 1)))
-        a.e("s_mov_b32 %s, %s" % (d_word(3, 2), N32))
         a.e("s_mov_b32 %s, 0x%08x" % (d_word(3, 3), RSRC_WORD3))
 
     def limb_offsets():
@@ -498,6 +531,8 @@ def build():
     a.e("s_cselect_b32 %s, -1, %s" % (TAG_A, TAG_A))
     a.e("s_cmp_eq_u32 %s, %s" % (OP[1], TAG_B))
     a.e("s_cselect_b32 %s, -1, %s" % (TAG_B, TAG_B))
+    a.e("s_cmp_eq_u32 %s, %s" % (OP[1], TAG_V))
+    a.e("s_cselect_b32 %s, -1, %s" % (TAG_V, TAG_V))
     a.e("s_lshr_b32 %s, %s, 29" % (T0, OP[1]))
     a.e("s_and_b32 %s, %s, 0x1fffffff" % (T1, OP[1]))
     a.e("s_lshl_b32 %s, %s, 13" % (T1, T1))

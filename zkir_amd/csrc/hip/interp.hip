@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "../../../include/zkir_hip.h"
 #include "device_structs.h"
 #include "fr32.cuh"
@@ -354,12 +356,14 @@ zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, ui
                         uint64_t n_vectors, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ outputs,
                         uint4* __restrict__ gslot_pool, uint32_t gslots_per_block,
                         uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats,
-                        uint32_t* __restrict__ work_counter) {
+                        uint32_t* __restrict__ work_counter, uint32_t victim_row) {
   __shared__ uint32_t next_item;
   const uint64_t gslots = (uint64_t)(uintptr_t)(gslot_pool + (size_t)blockIdx.x * gslots_per_block * 2 * kBlock);
   const uint32_t gslot_bytes = gslots_per_block * (uint32_t)(2 * kBlock * sizeof(uint4));
-  // the low half of a generic pointer into LDS is the LDS byte address
-  const uint32_t lds_base = (uint32_t)(uintptr_t)zkir_lds_slots;
+  // the low half of a generic pointer into LDS is the LDS byte address; with a victim row the
+  // first 8 KiB of the dynamic allocation are that row and the window slots follow
+  const uint32_t lds_base = (uint32_t)(uintptr_t)zkir_lds_slots + (victim_row ? 8192u : 0u);
+  const uint32_t evict_below = victim_row ? 0x20000000u : 0u;
   const uint32_t v_lo = (threadIdx.x >> 6) * 2048u + (threadIdx.x & 63u) * 16u;
   const uint32_t n4 = (uint32_t)n_vectors * 4u;
 
@@ -387,7 +391,7 @@ zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, ui
                  : [unsat] "=s"(wave_unsat), [first] "=v"(first_bad)
                  : [ops] "s"(ops), [n_ops] "s"(td.n_ops), [consts] "s"(consts), [n_consts] "s"(td.n_consts),
                    [gslots] "s"(gslots), [gslot_bytes] "s"(gslot_bytes), [lds_base] "s"(lds_base),
-                   [in_base] "s"(in_base), [out_base] "s"(out_base), [n4] "s"(n4), [live] "s"(live_mask), [v_lo] "v"(v_lo), [v_vec4] "v"(v_vec4)
+                   [in_base] "s"(in_base), [out_base] "s"(out_base), [n4] "s"(n4), [live] "s"(live_mask), [evict_below] "s"(evict_below), [v_lo] "v"(v_lo), [v_vec4] "v"(v_vec4)
                  : ZKIR_INTERP_CORE_CLOBBERS);
 
     if ((threadIdx.x & 63) == 0 && wave_unsat)
@@ -472,11 +476,22 @@ static const void* interp_entry(int variant) {
   }
 }
 
+// The generated stream parks evicted operands in one extra 8 KiB row of LDS when that row does
+// not cost a resident workgroup (five fit a CU up to 32 KiB each).
+static bool interp_victim_row(int variant, uint32_t lslots) {
+  static const bool off = std::getenv("ZKIR_NO_VICTIM_ROW") != nullptr;  // measurement aid
+  return variant == 2 && lslots + 1 <= 4 && !off;
+}
+// dynamic LDS of a workgroup: the window slots, plus the victim row
+static size_t interp_lds_bytes(int variant, uint32_t lslots) {
+  return (size_t)(lslots + (interp_victim_row(variant, lslots) ? 1 : 0)) * 2 * kBlock * sizeof(uint4);
+}
+
 hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
                          uint32_t* work_counter, uint32_t grid, hipStream_t stream) {
-  const size_t lds_bytes = (size_t)lslots * 2 * kBlock * sizeof(uint4);
+  const size_t lds_bytes = interp_lds_bytes(variant, lslots);
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (variant == 2 && n_vectors * 32 >= (1ull << 32)) return hipErrorInvalidValue;
   if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS limit the kernel must opt in
@@ -484,14 +499,15 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
     if (e != hipSuccess) return e;
   }
   uint4* pool = (uint4*)gslot_pool;
+  uint32_t victim_row = interp_victim_row(variant, lslots) ? 1u : 0u;  // read by the generated-stream kernel only
   void* args[] = {&tapes_dev, &n_tapes, &passes_per_tape, &n_vectors, &inputs, &outputs, &pool, &gslots_per_block,
-                  &unsat_per_tape, &stats, &work_counter};
+                  &unsat_per_tape, &stats, &work_counter, &victim_row};
   return hipLaunchKernel(interp_entry(variant), dim3(grid), dim3(kBlock), args, lds_bytes, stream);
 }
 
 // workgroups of the interpreter that fit on one CU with `lslots` window slots
 hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, int* blocks) {
-  const size_t lds_bytes = (size_t)lslots * 2 * kBlock * sizeof(uint4);
+  const size_t lds_bytes = interp_lds_bytes(variant, lslots);
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, interp_entry(variant), kBlock, lds_bytes);
   if (e == hipSuccess && *blocks < 1) *blocks = 1;
   return e;
