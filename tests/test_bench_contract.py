@@ -1,0 +1,48 @@
+"""The benchmark line committed under profiles/ (the output of `python bench.py` on an MI355X)
+carries every field the driver's contract names, with consistent values."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def latest_line():
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))
+    assert paths, "no committed bench line"
+    with open(paths[-1]) as f:
+        return json.loads(f.read())
+
+
+def test_bench_line_schema():
+    d = latest_line()
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
+                     ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # value is whole-job checks/s: constraints x vectors x steps over the timed region
+    cfg = d["config"]
+    per_step = cfg["n_constraints"] * cfg["vectors_per_gpu"] * d["n_gpus"]
+    assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # the counted products: one per Mul op and one per check, 128 high products each
+    fr = (cfg["n_mul_ops"] + cfg["n_constraints"]) * cfg["vectors_per_gpu"]
+    assert abs(r["achieved"] * 1e12 - 128.0 * fr / (r["kernel_ms"] * 1e-3)) / (r["achieved"] * 1e12) < 1e-6
+
+
+def test_traffic_file_matches_profiles():
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        t = json.load(f)
+    for key, ent in t.items():
+        if key.startswith("_"):
+            continue
+        assert os.path.exists(os.path.join(ROOT, ent["source"])), ent["source"]
+        want = ent["fetch_size_kb_raw"] * 2048 + ent["write_size_kb"] * 1024
+        assert abs(ent["bytes_per_launch"] - want) / want < 1e-6
