@@ -1,0 +1,68 @@
+"""Differential soak: random circuits under random generator / lowering options, GPU vs the C checker."""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import zkir_amd as z
+from zkir_amd import api
+from oracle import c_oracle as C
+from oracle import fr_ref as F
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+ctx = z.Context(0)
+rnd = random.Random(20240611)
+special = [0, 1, 2, F.P - 1, F.P - 2, F.HALF, F.HALF + 1, (1 << 64) - 1, 1 << 253, 253, 254, 255, F.P - 253, F.P - 254]
+done = rejected = bad = full = 0
+t0 = time.time()
+for it in range(N):
+    g = z.default_generator_config()
+    n = rnd.choice([20, 40, 80, 160, 320, 640])
+    g.min_instructions = g.max_instructions = n
+    g.max_expr_depth = rnd.choice([1, 1, 2, 3])
+    g.inputs_readable = 1
+    g.forced_inputs = rnd.choice([0, 1, 3, 8])
+    g.arithmetic_only = rnd.choice([0, 1, 1])
+    g.quadratic_aware = rnd.choice([0, 1, 1])
+    g.no_loops = rnd.choice([0, 1, 1])
+    g.safe_array_index = 1
+    g.enable_if = rnd.choice([0, 0, 2])
+    g.max_linear_terms = rnd.choice([0, 1])
+    g.signal_window = rnd.choice([0, 0, 4])
+    o = z.default_lower_options()
+    o.n_lslots = rnd.choice([0, 1, 2, 3, 4, 4, 8, 16])
+    o.use_acc = rnd.choice([0, 1, 1, 1])
+    o.reuse_slots = rnd.choice([0, 1, 1])
+    o.window_lifetime = rnd.choice([4, 16, 48, 200])
+    o.fold_constants = rnd.choice([0, 1])
+    o.bnot_variant = rnd.choice([0, 1])
+    o.max_iterations = 300
+    seed = rnd.randrange(1, 1 << 62)
+    try:
+        tape = z.Lowerer(z.Generator(seed, g).generate(), o).lower()
+    except api.LowerRejected:
+        rejected += 1
+        continue
+    nv = rnd.choice([1, 63, 64, 65, 200, 257, 513])
+    vecs = [[rnd.choice(special) if rnd.random() < 0.3 else rnd.randrange(F.P) for _ in range(tape.hdr.n_inputs)]
+            for _ in range(nv)]
+    inp = z.pack_inputs(vecs, tape.hdr.n_inputs)
+    for mode in ("", "compiled"):
+        if mode:
+            os.environ["ZKIR_INTERP"] = mode
+        else:
+            os.environ.pop("ZKIR_INTERP", None)
+        tid = ctx.upload(tape)
+        out, unsat, first, faults = ctx.eval_batch(tid, inp, nv)
+        ctx.release(tid)
+        o_c, u_c, first_c, f_c = C.eval_cpu(bytes(tape.hdr), tape.blob(), inp, nv, tape.hdr.n_outputs)
+        if not np.array_equal(out, o_c) or (unsat, first, faults) != (u_c, first_c, f_c):
+            bad += 1
+            print("MISMATCH seed", seed, "mode", mode or "default", "cfg", [getattr(g, k) for k, _ in g._fields_][:18],
+                  "opts", [getattr(o, k) for k, _ in o._fields_], "nv", nv, flush=True)
+    done += 1
+    codes = {c & 0xFF for c, _, _, _ in tape.ops()}
+    full += bool(codes - {0, 1, 2, 3, 4, 16, 17, 18, 48})
+    if it % 100 == 0:
+        print("iter", it, "evaluated", done, "rejected", rejected, "mismatches", bad, "%.0fs" % (time.time() - t0), flush=True)
+os.environ.pop("ZKIR_INTERP", None)
+print("SOAK done: evaluated %d circuits (%d with non-arithmetic operators), rejected %d, mismatches %d" % (done, full, rejected, bad))
+sys.exit(1 if bad else 0)
