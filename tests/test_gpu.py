@@ -165,6 +165,41 @@ def test_empty_batch_and_tape_without_inputs(ctx):
         ctx.release(tid)  # already released: an error code, not a crash
 
 
+def test_error_codes_not_crashes(ctx):
+    """Misuse of the device entry points comes back as an error code with a message."""
+    import ctypes
+    lib = api.lib
+    ops = [(F.OP_INPUT, G(0), I(0), NONE), (F.OP_OUTPUT, 0, G(0), NONE)]
+    tape = hand_tape(ops, [], 1, 1, 1, 0)
+    tid = ctx.upload(tape)
+    unsat, first = ctypes.c_uint64(), (ctypes.c_uint32 * 2)()
+    out = np.zeros((1, 8, 4), dtype=np.uint32)
+    # unknown tape id
+    rc = lib.zkir_eval_batch(ctx._h, 0x7FFFFFF0, None, 4, out.ctypes.data, ctypes.byref(unsat), first)
+    assert rc == api.E_INVALID and b"unknown tape" in lib.zkir_last_error(ctx._h)
+    # a tape with inputs, a batch, and no input pointer
+    rc = lib.zkir_eval_batch(ctx._h, tid, None, 4, out.ctypes.data, ctypes.byref(unsat), first)
+    assert rc == api.E_INVALID and b"inputs required" in lib.zkir_last_error(ctx._h)
+    # null result pointers, null context
+    assert lib.zkir_eval_batch(ctx._h, tid, None, 0, None, None, None) == api.E_INVALID
+    assert lib.zkir_eval_batch(None, tid, None, 0, None, ctypes.byref(unsat), first) == api.E_INVALID
+    assert lib.zkir_tape_upload(ctx._h, None, None, 0, None) == api.E_INVALID
+    # a tape whose op names a slot beyond the header's count never reaches the device
+    bad = bytearray(tape.blob())
+    bad[4:8] = struct.pack("<I", G(5))  # dst of the first op
+    tid2 = ctypes.c_uint32()
+    rc = lib.zkir_tape_upload(ctx._h, ctypes.byref(tape.hdr), bytes(bad), len(bad), ctypes.byref(tid2))
+    assert rc == api.E_INVALID and b"bad tape" in lib.zkir_last_error(ctx._h)
+    # the context still works afterwards
+    inp = z.pack_inputs([[7], [F.P - 1]], 1)
+    got, u, f, faults = ctx.eval_batch(tid, inp, 2)
+    assert z.unpack_outputs(got) == [[7], [F.P - 1]] and u == 0
+    ctx.release(tid)
+    # a device that does not exist
+    c = ctypes.c_void_p()
+    assert lib.zkir_ctx_create(1 << 20, ctypes.byref(c)) == api.E_INVALID and not c.value
+
+
 def test_generated_circuits_against_c_oracle(ctx):
     n_ok = 0
     for seed in range(1, 40):
