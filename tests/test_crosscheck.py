@@ -112,3 +112,16 @@ def test_emit_cli_without_gpu(tmp_path):
     assert X.main(["emit", "--seed", "2", "--vectors", "2", "--out", d, "--no-evaluate", "--extended"]) == 0
     assert json.load(open(os.path.join(d, "verdict.json")))["accepted"]
     assert sorted(os.listdir(d)) == ["circuit.circom", "input_0.json", "input_1.json", "run.sh", "verdict.json"]
+
+
+def test_verdict_comparison(tmp_path):
+    d = str(tmp_path / "ref")
+    assert X.main(["emit", "--seed", "2", "--vectors", "1", "--out", d, "--no-evaluate"]) == 0  # DoubleAssign here
+    with open(os.path.join(d, "circom.log"), "w") as f:
+        f.write("error[T3001]: Exception caused by invalid assignment: signal already assigned\n")
+    assert X.compare_verdict(d) == ("DoubleAssign", "DoubleAssign") and X.compare_case(d) == {}
+    with open(os.path.join(d, "circom.log"), "w") as f:
+        f.write("template instances: 1\nEverything went okay\n")
+    assert X.compare_case(d) == {"verdict": ["DoubleAssign", "Ok"]}
+    assert X.classify_circom_log("error[T3001]: Non quadratic constraints are not allowed!") == "NonQuadratic"
+    assert X.classify_circom_log("error[P1000]: something new") == "Other"

@@ -55,8 +55,8 @@ def expected_outputs(circuit, tape, outputs):
 
 RUN_SH = """#!/bin/sh
 # needs circom (>= 2.0) and snarkjs on PATH; run inside this directory
+circom circuit.circom --r1cs --wasm --sym > circom.log 2>&1 || { echo "circom refused the circuit (see circom.log)"; exit 0; }
 set -e
-circom circuit.circom --r1cs --wasm --sym
 for f in input_*.json; do
   k=${f#input_}; k=${k%.json}
   node circuit_js/generate_witness.js circuit_js/circuit.wasm "$f" "witness_$k.wtns"
@@ -181,6 +181,32 @@ def read_sym(path_or_text):
     return out
 
 
+# ---- verdicts -------------------------------------------------------------------------
+# Phrases of circom's compile errors, as recalled from its sources (unverified here), and the class
+# `lower` gives the same circuit.  A circuit both sides refuse for the same reason is an agreement.
+CIRCOM_ERRORS = [
+    ("Non quadratic constraints are not allowed", "NonQuadratic"),
+    ("signal already assigned", "DoubleAssign"),
+    ("Signal already assigned", "DoubleAssign"),
+    ("Out of bounds", "OOBIndex"),
+    ("out of bounds", "OOBIndex"),
+    ("Division by zero", "DivByZero"),
+    ("division by zero", "DivByZero"),
+    ("can be unknown during the constraint generation phase", "UnknownControl"),
+    ("Non-quadratic constraint was detected statically", "NonQuadratic"),
+    ("depends on the value of the condition", "UnknownControl"),
+]
+
+
+def classify_circom_log(text):
+    """The class named by circom's compile log: "Ok" when it reports no error, one of lower's class
+    names for a recognised error, "Other" for an error this table does not know."""
+    for phrase, cls in CIRCOM_ERRORS:
+        if phrase in text:
+            return cls
+    return "Other" if "error" in text.lower() else "Ok"
+
+
 # ---- comparison --------------------------------------------------------------------
 def failed_constraints(r1cs, witness):
     """Indices of the R1CS constraints the witness does not satisfy (big integers)."""
@@ -205,8 +231,24 @@ def compare_outputs(sym, witness, expected, component="main"):
     return bad
 
 
+def compare_verdict(directory):
+    """(this evaluator's class, circom's class) for the circuit in `directory`, after run.sh."""
+    with open(os.path.join(directory, "verdict.json")) as f:
+        ours = json.load(f)["class"]
+    log = os.path.join(directory, "circom.log")
+    theirs = classify_circom_log(open(log).read()) if os.path.exists(log) else None
+    return ("Ok" if ours == "OK" else ours), theirs
+
+
 def compare_case(directory):
-    """After run.sh: {vector: {"outputs": [...], "constraints": [...]}} for the vectors that disagree."""
+    """After run.sh: {vector: {"outputs": [...], "constraints": [...]}} for the vectors that disagree
+    (and {"verdict": (ours, circom's)} when the two sides classify the circuit differently)."""
+    if os.path.exists(os.path.join(directory, "verdict.json")) and os.path.exists(os.path.join(directory, "circom.log")):
+        ours, theirs = compare_verdict(directory)
+        if ours != theirs:
+            return {"verdict": [ours, theirs]}
+        if ours != "Ok":
+            return {}
     sym = read_sym(os.path.join(directory, "circuit.sym"))
     r1cs_path = os.path.join(directory, "circuit.r1cs")
     r1cs = read_r1cs(r1cs_path) if os.path.exists(r1cs_path) else None
