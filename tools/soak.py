@@ -11,7 +11,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 ctx = z.Context(0)
 rnd = random.Random(20240611)
 special = [0, 1, 2, F.P - 1, F.P - 2, F.HALF, F.HALF + 1, (1 << 64) - 1, 1 << 253, 253, 254, 255, F.P - 253, F.P - 254]
-done = rejected = bad = full = 0
+done = rejected = bad = full = multi = 0
+group = []
 t0 = time.time()
 for it in range(N):
     g = z.default_generator_config()
@@ -58,11 +59,41 @@ for it in range(N):
             bad += 1
             print("MISMATCH seed", seed, "mode", mode or "default", "cfg", [getattr(g, k) for k, _ in g._fields_][:18],
                   "opts", [getattr(o, k) for k, _ in o._fields_], "nv", nv, flush=True)
+    # every so often the recent tapes also go through one multi-tape launch, one of them broken
+    group.append(tape)
+    if len(group) == 12:
+        nv2 = rnd.choice([1, 64, 130, 300])
+        k = rnd.randrange(len(group))
+        ops = group[k].ops()
+        muls = [i for i, op in enumerate(ops) if (op[0] & 0xFF) == F.OP_MUL]
+        if muls:  # turn a product into a sum: constraints that use it stop holding (most of the time)
+            j = rnd.choice(muls)
+            ops[j] = (F.OP_ADD,) + ops[j][1:]
+            import struct
+            blob = b"".join(struct.pack("<4I", *op) for op in ops) + group[k].blob()[16 * len(ops):]
+            group[k] = z.Tape.from_parts(group[k].hdr, blob)
+        blocks, want = [], []
+        for t in group:
+            v2 = [[rnd.choice(special) if rnd.random() < 0.3 else rnd.randrange(F.P) for _ in range(t.hdr.n_inputs)]
+                  for _ in range(nv2)]
+            i2 = z.pack_inputs(v2, t.hdr.n_inputs)
+            blocks.append(i2.reshape(-1))
+            want.append(C.eval_cpu(bytes(t.hdr), t.blob(), i2, nv2, t.hdr.n_outputs, want_outputs=False)[1])
+        tids = [ctx.upload(t) for t in group]
+        got, _ = ctx.eval_multi(tids, np.concatenate(blocks) if blocks else None, nv2)
+        for t in tids:
+            ctx.release(t)
+        if got != want:
+            bad += 1
+            print("MISMATCH in a multi-tape launch at iteration", it, got, want, flush=True)
+        multi += 1
+        group = []
     done += 1
     codes = {c & 0xFF for c, _, _, _ in tape.ops()}
     full += bool(codes - {0, 1, 2, 3, 4, 16, 17, 18, 48})
     if it % 100 == 0:
         print("iter", it, "evaluated", done, "rejected", rejected, "mismatches", bad, "%.0fs" % (time.time() - t0), flush=True)
 os.environ.pop("ZKIR_INTERP", None)
-print("SOAK done: evaluated %d circuits (%d with non-arithmetic operators), rejected %d, mismatches %d" % (done, full, rejected, bad))
+print("SOAK done: evaluated %d circuits (%d with non-arithmetic operators) and %d multi-tape launches, rejected %d, "
+      "mismatches %d" % (done, full, multi, rejected, bad))
 sys.exit(1 if bad else 0)

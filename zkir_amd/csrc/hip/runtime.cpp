@@ -132,6 +132,8 @@ int32_t arena_alloc(zkir_ctx* ctx, size_t bytes, void** out, int* slab_out) {
 uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, int variant, uint32_t lslots) {
   int per_cu = 2;
   if (zkir::interp_blocks_per_cu(variant, lslots, &per_cu) != hipSuccess) per_cu = 2;
+  if (const char* cap = std::getenv("ZKIR_BLOCKS_PER_CU"))  // measurement aid: fewer resident workgroups
+    per_cu = std::max(1, std::min(per_cu, std::atoi(cap)));
   const uint64_t g = (uint64_t)ctx->n_cu * (uint64_t)per_cu;
   return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, work_items));
 }
