@@ -439,6 +439,41 @@ def test_deep_gadget_full_size(ctx):
     ctx.release(tid)
 
 
+def test_batch_beyond_the_generated_stream_limit(ctx):
+    """32*N no longer fits 32 bits: the launch takes the compiled kernel (64-bit offsets), same results."""
+    torch = pytest.importorskip("torch")
+    ops = [(F.OP_INPUT, G(0), I(0), NONE), (F.OP_MUL, G(1), G(0), K(0)), (F.OP_CHECK, G(1), G(0), K(0)),
+           (F.OP_CHECK, G(0), G(0), K(1))]  # x*3 == x*3 holds; x*1 == x holds
+    tape = hand_tape(ops, [3, 1], 1, 0, 2, 0)
+    n = (1 << 27) + 5
+    dev = torch.device("cuda:0")
+    inp = torch.empty((1, 8, n), dtype=torch.int32, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2)
+    for l in range(8):  # limb by limb: a full-size int64 temporary would be 8 GiB
+        inp[0, l] = torch.randint(0, 1 << 32, (n,), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+    inp[0, 7] &= 0x0FFFFFFF
+    res = torch.zeros(4, dtype=torch.int64, device=dev)
+    tid = ctx.upload(tape)
+    ctx.eval_batch_dev(tid, inp.data_ptr(), n, None, res.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    r = res.cpu().numpy().view(np.uint64)
+    assert r[0] == 0 and r[1] == np.uint64(0xFFFFFFFFFFFFFFFF)
+    # the same tape with the wrong constant in its check fails for every vector whose input is not 0
+    bad = hand_tape([(F.OP_INPUT, G(0), I(0), NONE), (F.OP_MUL, G(1), G(0), K(0)), (F.OP_CHECK, G(1), G(0), K(1))],
+                    [3, 1], 1, 0, 2, 0)
+    tid2 = ctx.upload(bad)
+    ctx.eval_batch_dev(tid2, inp.data_ptr(), n, None, res.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    r = res.cpu().numpy().view(np.uint64)
+    zeros = int((inp[0] == 0).all(dim=0).sum())
+    assert int(r[0]) == n - zeros
+    ctx.release(tid)
+    ctx.release(tid2)
+    del inp
+    torch.cuda.empty_cache()
+
+
 def test_measured_rates_are_sane(ctx):
     mulhi = ctx.int_mul_rate(0)
     assert 5e12 < mulhi < 6e13
