@@ -42,6 +42,7 @@ extern "C" {
 #define ZKIR_E_BUFSIZE (-6)   /* caller buffer too small; *needed is set     */
 #define ZKIR_E_LIMIT (-7)     /* size beyond a documented maximum            */
 #define ZKIR_E_INTERNAL (-8)  /* a host-side exception was caught at the ABI */
+#define ZKIR_E_UNSUPPORTED (-9) /* the circuit uses a construct this backend cannot express */
 
 /* ------------------------------------------------------------- tape format */
 /*
@@ -211,6 +212,12 @@ int32_t zkir_circuit_print(const zkir_circuit* c, char* buf, size_t cap, size_t*
 
 /* CircomTranspiler::transpile_circuit (src/circom.rs:412-429). */
 int32_t zkir_circuit_transpile_circom(const zkir_circuit* c, char* buf, size_t cap, size_t* needed);
+
+/* NoirTranspiler::transpile_circuit: the second backend the reference names as a goal
+ * (README.md:5,10; no reference code).  Same call shape as the Circom backend
+ * (src/circom.rs:4-15,412).  ZKIR_E_UNSUPPORTED when the circuit uses an operator or loop
+ * Noir's Field type cannot express; zkir_host_last_error names it. */
+int32_t zkir_circuit_transpile_noir(const zkir_circuit* c, char* buf, size_t cap, size_t* needed);
 
 /* `{:#?}` of circuit.instructions as src/main.rs:91 prints it. */
 int32_t zkir_circuit_debug(const zkir_circuit* c, char* buf, size_t cap, size_t* needed);

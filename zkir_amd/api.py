@@ -15,7 +15,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libzkir_hip.so")
 
-OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_LOWER, E_BUFSIZE, E_LIMIT, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8
+OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_LOWER, E_BUFSIZE, E_LIMIT, E_INTERNAL, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 LOWER_CLASSES = {0: "OK", 1: "DoubleAssign", 2: "OOBIndex", 3: "DivByZero", 4: "NonQuadratic", 5: "LoopCap",
                  6: "UnknownControl", 7: "UninitSignal", 8: "BadAst"}
 
@@ -74,6 +74,7 @@ def _load():
         "zkir_circuit_parse": [c_char_p, P(c_void_p)],
         "zkir_circuit_print": [c_void_p, c_char_p, c_size_t, P(c_size_t)],
         "zkir_circuit_transpile_circom": [c_void_p, c_char_p, c_size_t, P(c_size_t)],
+        "zkir_circuit_transpile_noir": [c_void_p, c_char_p, c_size_t, P(c_size_t)],
         "zkir_circuit_debug": [c_void_p, c_char_p, c_size_t, P(c_size_t)],
         "zkir_gadget_poseidon_style": [c_uint32, c_uint32, c_uint64, P(c_void_p)],
         "zkir_lower_options_default": [P(LowerOptions)],
@@ -197,6 +198,18 @@ class CircomTranspiler:
 
     def transpile_circuit(self):
         return _text(lib.zkir_circuit_transpile_circom, self.circuit._h)
+
+
+class NoirTranspiler:
+    """The second backend the reference names as a goal (README.md:5,10): same call shape as
+    CircomTranspiler.  Raises ZkirError with code E_UNSUPPORTED for circuits that use an operator
+    or loop Noir's Field type cannot express."""
+
+    def __init__(self, circuit):
+        self.circuit = circuit
+
+    def transpile_circuit(self):
+        return _text(lib.zkir_circuit_transpile_noir, self.circuit._h)
 
 
 def poseidon_style_gadget(width, rounds, seed):

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzkir_hip.so")
 
 DEVICE_SOURCES = ["hip/interp.hip"]
-HOST_SOURCES = ["hip/runtime.cpp", "host/capi.cpp", "host/generator.cpp", "host/circom.cpp", "host/lower.cpp",
+HOST_SOURCES = ["hip/runtime.cpp", "host/capi.cpp", "host/generator.cpp", "host/circom.cpp", "host/noir.cpp", "host/lower.cpp",
                 "host/sexpr.cpp", "host/gadget.cpp", "host/fr_host.cpp"]
 
 

@@ -8,6 +8,7 @@
 #include "../hip/tape_check.h"
 #include "ast.hpp"
 #include "circom.hpp"
+#include "noir.hpp"
 #include "gadget.hpp"
 #include "generator.hpp"
 #include "lower.hpp"
@@ -32,6 +33,9 @@ int32_t guarded(F f) {
   } catch (const zkir::LowerError& e) {
     g_host_error = e.what();
     return ZKIR_E_LOWER;
+  } catch (const zkir::NoirUnsupported& e) {
+    g_host_error = e.what();
+    return ZKIR_E_UNSUPPORTED;
   } catch (const std::bad_alloc&) {
     g_host_error = "out of memory";
     return ZKIR_E_NOMEM;
@@ -121,6 +125,14 @@ int32_t zkir_circuit_transpile_circom(const zkir_circuit* c, char* buf, size_t c
   if (!c) return ZKIR_E_INVALID;
   return guarded([&]() -> int32_t {
     zkir::CircomTranspiler t(c->circuit);
+    return copy_out(t.transpile_circuit(), buf, cap, needed);
+  });
+}
+
+int32_t zkir_circuit_transpile_noir(const zkir_circuit* c, char* buf, size_t cap, size_t* needed) {
+  if (!c) return ZKIR_E_INVALID;
+  return guarded([&]() -> int32_t {
+    zkir::NoirTranspiler t(c->circuit);
     return copy_out(t.transpile_circuit(), buf, cap, needed);
   });
 }
