@@ -55,12 +55,28 @@ extern "C" {
  *     zkir_op   ops[n_ops]
  *     uint32_t  consts[n_consts][8]        canonical limbs
  *     uint32_t  triples[n_constraints][3]  operands (a, b, c): w[a]*w[b]==w[c]
+ *
+ * Strand tapes (flags & ZKIR_TAPE_F_STRANDS).  A circuit whose ops are not one
+ * dependent chain can be cut into ZKIR_STRANDS op streams that run side by side, one
+ * wavefront each, on the SAME 64 input vectors (instead of four wavefronts on 256
+ * vectors): the shape for batches too small to fill the machine.  ops[] then holds
+ * strand 0's ops, then strand 1's, ... (strand_ops[] each).  Every strand has its own
+ * accumulator and its own GSLOT / LSLOT slots; values cross between strands only through
+ * XSLOT operands, and only across a ZKIR_OP_BARRIER: a strand may read an exchange slot
+ * another strand wrote only after both have passed the same barrier, and may overwrite
+ * it only after a barrier that every reader of the old value has reached.  All strands
+ * hold the same number of barriers.  Constraint numbers ride in the CHECK ops
+ * (bits 8..31 of `code` = constraint number + 1), since a strand sees only its own checks.
  */
+#define ZKIR_TAPE_F_STRANDS 1u
+#define ZKIR_STRANDS 4u
+#define ZKIR_MAX_XSLOTS 32u
 #define ZKIR_TAPE_MAGIC 0x31544b5au /* "ZKT1" */
 #define ZKIR_TAPE_VERSION 1u
 
 typedef struct zkir_op {
-  uint32_t code; /* zkir_opcode in bits 0..7; bits 8..31 reserved (0)       */
+  uint32_t code; /* zkir_opcode in bits 0..7; bits 8..31: 0, or in a strand
+                    tape's CHECK op the constraint number + 1                */
   uint32_t dst;  /* operand (kind GSLOT / LSLOT / NONE), or a raw index for
                     ZKIR_OP_OUTPUT (output element) and the `c` operand for
                     ZKIR_OP_CHECK                                            */
@@ -77,6 +93,7 @@ typedef struct zkir_op {
 #define ZKIR_KIND_INPUT 3u /* input element (only as `a` of ZKIR_OP_INPUT)    */
 #define ZKIR_KIND_ACC 4u   /* the previous op's result, still in registers    */
 #define ZKIR_KIND_NONE 5u  /* no operand / result is not stored               */
+#define ZKIR_KIND_XSLOT 6u /* exchange slot shared by the strands (strand tapes) */
 #define ZKIR_OPERAND(kind, idx) (((uint32_t)(kind) << ZKIR_KIND_SHIFT) | ((uint32_t)(idx) & ZKIR_INDEX_MASK))
 #define ZKIR_OPERAND_NONE ZKIR_OPERAND(ZKIR_KIND_NONE, 0)
 #define ZKIR_OPERAND_ACC ZKIR_OPERAND(ZKIR_KIND_ACC, 0)
@@ -94,6 +111,7 @@ typedef enum zkir_opcode {
   ZKIR_OP_NEG = 4,     /* dst = -a mod p                 (emitted by lower only)        */
   ZKIR_OP_BNOT = 5,    /* ~a over 254 bits, then mod p   (circom.rs:136)                */
   ZKIR_OP_BNOT256 = 6, /* ~a over 256 bits, then mod p   (alternative reading of `~`)   */
+  ZKIR_OP_BARRIER = 7, /* strand tapes: wait for the other strands (no operands)        */
   /* binary */
   ZKIR_OP_ADD = 16,  /* circom.rs:35-41   */
   ZKIR_OP_SUB = 17,  /* circom.rs:42-46   */
@@ -131,9 +149,10 @@ typedef struct zkir_tape_hdr {
   uint32_t n_lslots;      /* on-chip window slots (<= ZKIR_MAX_LSLOTS)          */
   uint32_t n_constraints; /* number of ZKIR_OP_CHECK ops                        */
   uint32_t n_mul_ops;     /* ZKIR_OP_MUL ops (work accounting only)             */
-  uint32_t flags;
-  uint32_t reserved[5];
-} zkir_tape_hdr; /* 64 bytes */
+  uint32_t flags;         /* ZKIR_TAPE_F_*                                      */
+  uint32_t strand_ops[4]; /* strand tapes: ops of each strand (sum = n_ops); else 0 */
+  uint32_t n_xslots;      /* strand tapes: exchange slots (<= ZKIR_MAX_XSLOTS)  */
+} zkir_tape_hdr; /* 64 bytes; n_gslots / n_lslots of a strand tape are per strand */
 
 #define ZKIR_MAX_LSLOTS 16u
 

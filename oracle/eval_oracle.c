@@ -27,11 +27,12 @@ typedef struct { uint64_t w[4]; } fe;
 typedef struct { uint32_t code, dst, a, b; } op_t;
 typedef struct {
   uint32_t magic, version, n_inputs, n_outputs, n_consts, n_ops, n_gslots, n_lslots, n_constraints, n_mul_ops, flags,
-      reserved[5];
+      strand_ops[4], n_xslots;
 } hdr_t;
-enum { K_GSLOT = 0, K_LSLOT = 1, K_CONST = 2, K_INPUT = 3, K_ACC = 4, K_NONE = 5 };
+enum { K_GSLOT = 0, K_LSLOT = 1, K_CONST = 2, K_INPUT = 3, K_ACC = 4, K_NONE = 5, K_XSLOT = 6 };
+enum { F_STRANDS = 1, STRANDS = 4 };
 enum {
-  OP_NOP = 0, OP_INPUT = 1, OP_OUTPUT = 2, OP_COPY = 3, OP_NEG = 4, OP_BNOT = 5, OP_BNOT256 = 6,
+  OP_NOP = 0, OP_INPUT = 1, OP_OUTPUT = 2, OP_COPY = 3, OP_NEG = 4, OP_BNOT = 5, OP_BNOT256 = 6, OP_BARRIER = 7,
   OP_ADD = 16, OP_SUB, OP_MUL, OP_POW, OP_DIV, OP_IDIV, OP_REM, OP_LT, OP_LE, OP_GT, OP_GE, OP_EQ, OP_AND, OP_OR,
   OP_BAND, OP_BOR, OP_BXOR, OP_SHR, OP_SHL,
   OP_CHECK = 48
@@ -206,46 +207,76 @@ static void store_soa(uint32_t* base, uint64_t N, uint64_t elem, uint64_t t, con
   for (int i = 0; i < 4; i++) { q[(2 * i) * N] = (uint32_t)v->w[i]; q[(2 * i + 1) * N] = (uint32_t)(v->w[i] >> 32); }
 }
 
+/*
+ * One vector at a time.  A plain tape is one op stream.  A strand tape (flags & F_STRANDS)
+ * is STRANDS op streams with private accumulators and private G / L slots that share the
+ * exchange slots x[]; they are run here one after the other from barrier to barrier, which
+ * is one of the interleavings the tape's rules allow (a strand reads an exchange slot only
+ * after the barrier that follows its write), so any correct parallel run gives the same values.
+ * The constraint number of a CHECK is its position in a plain tape, (code >> 8) - 1 in a strand tape.
+ */
 static void* run_range(void* arg) {
   job_t* j = (job_t*)arg;
   const hdr_t* h = j->h;
-  fe* g = (fe*)malloc(sizeof(fe) * (h->n_gslots + 1));
-  fe l[16], acc = {{0, 0, 0, 0}}, one = {{1, 0, 0, 0}};
+  const int strands = (h->flags & F_STRANDS) ? STRANDS : 1;
+  fe* gbuf = (fe*)malloc(sizeof(fe) * ((size_t)h->n_gslots + 1) * (size_t)strands);
+  fe lbuf[STRANDS][16], accs[STRANDS], x[64], one = {{1, 0, 0, 0}};
+  uint32_t begin[STRANDS + 1];
+  begin[0] = 0;
+  for (int s = 0; s < strands; s++) begin[s + 1] = strands == 1 ? h->n_ops : begin[s] + h->strand_ops[s];
   j->unsat = j->faults = 0;
   j->first_vec = j->first_con = ~0ull;
   for (uint64_t t = j->lo; t < j->hi; t++) {
-    uint64_t k = 0;
-    int faulted = 0;
-    for (uint32_t pc = 0; pc < h->n_ops; pc++) {
-      const op_t* op = &j->ops[pc];
-      const uint32_t code = op->code & 0xff;
+    uint64_t k = 0, first_k = ~0ull;
+    int faulted = 0, running = strands;
+    uint32_t pcs[STRANDS];
+    for (int s = 0; s < strands; s++) { pcs[s] = begin[s]; memset(&accs[s], 0, sizeof(fe)); }
+    while (running) {
+      running = 0;
+      for (int s = 0; s < strands; s++) {
+        fe* g = gbuf + (size_t)s * ((size_t)h->n_gslots + 1);
+        fe* l = lbuf[s];
+        fe acc = accs[s];
+        uint32_t pc = pcs[s];
+        for (; pc < begin[s + 1]; pc++) {
+          const op_t* op = &j->ops[pc];
+          const uint32_t code = op->code & 0xff;
 #define SRC(o) ((o) >> 29 == K_GSLOT ? &g[(o) & 0x1fffffff] : (o) >> 29 == K_LSLOT ? &l[(o) & 0x1fffffff] : \
-                (o) >> 29 == K_CONST ? &j->consts_m[(o) & 0x1fffffff] : &acc)
-      if (code == OP_NOP) continue;
-      if (code == OP_INPUT) {
-        fe x; load_soa(&x, j->in, j->N, op->a & 0x1fffffff, t); to_mont(&acc, &x);
-      } else if (code == OP_OUTPUT) {
-        if (j->out) { fe x; f_mul(&x, SRC(op->a), &one); store_soa(j->out, j->N, op->dst, t, &x); }
-        continue;
-      } else if (code == OP_CHECK) {
-        fe x; f_mul(&x, SRC(op->a), SRC(op->b));
-        if (!eq(&x, SRC(op->dst))) {
-          j->unsat++;
-          if (j->first_vec == ~0ull) { j->first_vec = t; j->first_con = k; }
+                (o) >> 29 == K_CONST ? &j->consts_m[(o) & 0x1fffffff] : (o) >> 29 == K_XSLOT ? &x[(o) & 63] : &acc)
+          if (code == OP_NOP) continue;
+          if (code == OP_BARRIER) { pc++; break; }
+          if (code == OP_INPUT) {
+            fe v; load_soa(&v, j->in, j->N, op->a & 0x1fffffff, t); to_mont(&acc, &v);
+          } else if (code == OP_OUTPUT) {
+            if (j->out) { fe v; f_mul(&v, SRC(op->a), &one); store_soa(j->out, j->N, op->dst, t, &v); }
+            continue;
+          } else if (code == OP_CHECK) {
+            fe v; f_mul(&v, SRC(op->a), SRC(op->b));
+            const uint64_t id = strands == 1 ? k : (uint64_t)(op->code >> 8) - 1;
+            if (!eq(&v, SRC(op->dst))) {
+              j->unsat++;
+              if (id < first_k) first_k = id;
+            }
+            k++;
+            continue;
+          } else {
+            fe r;
+            faulted |= apply(code, &r, SRC(op->a), code >= OP_ADD ? SRC(op->b) : NULL);
+            acc = r;
+          }
+          if (op->dst >> 29 == K_GSLOT) g[op->dst & 0x1fffffff] = acc;
+          else if (op->dst >> 29 == K_LSLOT) l[op->dst & 0x1fffffff] = acc;
+          else if (op->dst >> 29 == K_XSLOT) x[op->dst & 63] = acc;
         }
-        k++;
-        continue;
-      } else {
-        fe r;
-        faulted |= apply(code, &r, SRC(op->a), code >= OP_ADD ? SRC(op->b) : NULL);
-        acc = r;
+        accs[s] = acc;
+        pcs[s] = pc;
+        if (pc < begin[s + 1]) running = 1;
       }
-      if (op->dst >> 29 == K_GSLOT) g[op->dst & 0x1fffffff] = acc;
-      else if (op->dst >> 29 == K_LSLOT) l[op->dst & 0x1fffffff] = acc;
     }
+    if (first_k != ~0ull && j->first_vec == ~0ull) { j->first_vec = t; j->first_con = first_k; }
     j->faults += (uint64_t)faulted;
   }
-  free(g);
+  free(gbuf);
   return NULL;
 }
 
@@ -258,7 +289,7 @@ static void* run_range(void* arg) {
 int zkir_eval_cpu(const void* hdr, const void* blob, const uint32_t* inputs_soa, uint64_t N, uint32_t* outputs_soa,
                   uint64_t* unsat_count, uint32_t* first_unsat, uint64_t* faults, int n_threads) {
   const hdr_t* h = (const hdr_t*)hdr;
-  if (!h || h->n_lslots > 16 || n_threads < 1 || n_threads > 1024) return -1;
+  if (!h || h->n_lslots > 16 || h->n_xslots > 64 || n_threads < 1 || n_threads > 1024) return -1;
   const op_t* ops = (const op_t*)blob;
   const uint32_t* craw = (const uint32_t*)((const char*)blob + (size_t)h->n_ops * 16);
   fe* cm = (fe*)malloc(sizeof(fe) * (h->n_consts + 1));

@@ -141,7 +141,7 @@ def neg(a):
 
 
 # opcode numbers of include/zkir_hip.h
-OP_NOP, OP_INPUT, OP_OUTPUT, OP_COPY, OP_NEG, OP_BNOT, OP_BNOT256 = 0, 1, 2, 3, 4, 5, 6
+OP_NOP, OP_INPUT, OP_OUTPUT, OP_COPY, OP_NEG, OP_BNOT, OP_BNOT256, OP_BARRIER = 0, 1, 2, 3, 4, 5, 6, 7
 (OP_ADD, OP_SUB, OP_MUL, OP_POW, OP_DIV, OP_IDIV, OP_REM, OP_LT, OP_LE, OP_GT, OP_GE, OP_EQ, OP_AND, OP_OR,
  OP_BAND, OP_BOR, OP_BXOR, OP_SHR, OP_SHL) = range(16, 35)
 OP_CHECK = 48
@@ -163,66 +163,90 @@ OP_NAMES = {
 
 KIND_SHIFT = 29
 INDEX_MASK = 0x1FFFFFFF
-K_GSLOT, K_LSLOT, K_CONST, K_INPUT, K_ACC, K_NONE = 0, 1, 2, 3, 4, 5
+K_GSLOT, K_LSLOT, K_CONST, K_INPUT, K_ACC, K_NONE, K_XSLOT = 0, 1, 2, 3, 4, 5, 6
 
 
 def operand(kind, idx=0):
     return (kind << KIND_SHIFT) | (idx & INDEX_MASK)
 
 
-def eval_tape_one(ops, consts, inputs):
+def eval_tape_one(ops, consts, inputs, strand_ops=None):
     """Interpret a tape for ONE input vector with big integers.
 
     ops: iterable of (code, dst, a, b); consts / inputs: lists of ints in [0, p).
-    Returns (outputs dict, unsat constraint indices, faults).
+    strand_ops: for a strand tape, the number of ops of each strand (ops holds the strands one
+    after the other).  The strands have private accumulators and G / L slots, share the exchange
+    slots, and are run here one after the other from barrier to barrier; constraint numbers
+    then come from the CHECK ops ((code >> 8) - 1) instead of their position.
+    Returns (outputs dict, unsat constraint indices in ascending order, faults).
     """
-    g, l, acc = {}, {}, 0
+    ops = list(ops)
+    counts = list(strand_ops) if strand_ops else [len(ops)]
+    begin = [sum(counts[:i]) for i in range(len(counts) + 1)]
+    state = [{"g": {}, "l": {}, "acc": 0, "pc": begin[i]} for i in range(len(counts))]
+    xs = {}
     outputs, unsat, faults, k = {}, [], 0, 0
 
-    def rd(o):
+    def rd(st, o):
         kind, idx = o >> KIND_SHIFT, o & INDEX_MASK
         if kind == K_GSLOT:
-            return g[idx]
+            return st["g"][idx]
         if kind == K_LSLOT:
-            return l[idx]
+            return st["l"][idx]
         if kind == K_CONST:
             return consts[idx]
         if kind == K_ACC:
-            return acc
+            return st["acc"]
+        if kind == K_XSLOT and strand_ops:
+            return xs[idx]
         raise ValueError("bad source operand kind %d" % kind)
 
-    def wr(o, v):
+    def wr(st, o, v):
         kind, idx = o >> KIND_SHIFT, o & INDEX_MASK
         if kind == K_GSLOT:
-            g[idx] = v
+            st["g"][idx] = v
         elif kind == K_LSLOT:
-            l[idx] = v
+            st["l"][idx] = v
+        elif kind == K_XSLOT and strand_ops:
+            xs[idx] = v
         elif kind != K_NONE:
             raise ValueError("bad destination operand kind %d" % kind)
 
-    for code, dst, a, b in ops:
-        code &= 0xFF
-        if code == OP_NOP:
-            continue
-        if code == OP_INPUT:
-            assert a >> KIND_SHIFT == K_INPUT
-            acc = inputs[a & INDEX_MASK]
-            wr(dst, acc)
-        elif code == OP_OUTPUT:
-            outputs[dst] = rd(a)
-        elif code == OP_CHECK:
-            if mul(rd(a), rd(b)) != rd(dst):
-                unsat.append(k)
-            k += 1
-        elif code in UNARY:
-            acc = UNARY[code](rd(a))
-            wr(dst, acc)
-        elif code in BINARY:
-            try:
-                acc = BINARY[code](rd(a), rd(b))
-            except Fault:
-                acc, faults = 0, faults + 1
-            wr(dst, acc)
-        else:
-            raise ValueError("bad opcode %d" % code)
-    return outputs, unsat, faults
+    running = True
+    while running:
+        running = False
+        for i, st in enumerate(state):
+            while st["pc"] < begin[i + 1]:
+                full, dst, a, b = ops[st["pc"]]
+                st["pc"] += 1
+                code = full & 0xFF
+                if code == OP_NOP:
+                    continue
+                if code == OP_BARRIER:
+                    if not strand_ops:
+                        raise ValueError("BARRIER in a plain tape")
+                    break
+                if code == OP_INPUT:
+                    assert a >> KIND_SHIFT == K_INPUT
+                    st["acc"] = inputs[a & INDEX_MASK]
+                    wr(st, dst, st["acc"])
+                elif code == OP_OUTPUT:
+                    outputs[dst] = rd(st, a)
+                elif code == OP_CHECK:
+                    if mul(rd(st, a), rd(st, b)) != rd(st, dst):
+                        unsat.append((full >> 8) - 1 if strand_ops else k)
+                    k += 1
+                elif code in UNARY:
+                    st["acc"] = UNARY[code](rd(st, a))
+                    wr(st, dst, st["acc"])
+                elif code in BINARY:
+                    try:
+                        st["acc"] = BINARY[code](rd(st, a), rd(st, b))
+                    except Fault:
+                        st["acc"], faults = 0, faults + 1
+                    wr(st, dst, st["acc"])
+                else:
+                    raise ValueError("bad opcode %d" % code)
+            if st["pc"] < begin[i + 1]:
+                running = True
+    return outputs, sorted(unsat), faults

@@ -93,6 +93,7 @@ class Lane:
         self.v, self.s = {}, {}
         self.vcc, self.scc, self.exec = 0, 0, M64
         self.pending = {}  # register -> "vm" | "lgkm": a load not yet waited for
+        self.stores_waited = True  # no store (LDS or device memory) issued since the last full wait
         self.steps = 0
         self.counts = {}
 
@@ -246,8 +247,10 @@ class Lane:
         return base + soffset + off
 
     # ---- execution -------------------------------------------------------------
-    def run(self, prog, labels, max_steps=50_000_000):
-        pc = 0
+    def run(self, prog, labels, max_steps=50_000_000, pc=0, stop_at_barrier=False):
+        """Run from `pc` to the end of the program.  With stop_at_barrier the run also ends after
+        an s_barrier and returns the index of the next instruction (None at the end of the
+        program): the caller interleaves the wavefronts of a workgroup that way."""
         while pc < len(prog):
             op, a, mods = prog[pc]
             self.steps += 1
@@ -255,8 +258,11 @@ class Lane:
                 raise ModelError("step limit reached: the stream does not terminate")
             self.counts[op] = self.counts.get(op, 0) + 1
             pc = self.step(op, a, mods, pc, labels)
+            if op == "s_barrier" and stop_at_barrier:
+                return pc
         if self.pending:
             raise ModelError("loads still in flight at the end: %s" % sorted(self.pending))
+        return None
 
     def step(self, op, a, mods, pc, labels):
         nxt = pc + 1
@@ -323,6 +329,12 @@ class Lane:
                 nxt = labels[a[0]]
         elif op == "s_nop":
             pass
+        elif op == "s_barrier":
+            # what another wavefront is to see must have left this one: no memory operation in flight
+            if self.pending:
+                raise ModelError("s_barrier with loads in flight: %s" % sorted(self.pending))
+            if not self.stores_waited:
+                raise ModelError("s_barrier with stores not waited for")
         elif op == "s_waitcnt":
             kinds = []
             for tok in a + mods:
@@ -331,6 +343,8 @@ class Lane:
                     raise ModelError("only zero-count waits are modelled: " + tok)
                 kinds.append("vm" if m.group(1) == "vmcnt" else "lgkm")
             self.pending = {r: k for r, k in self.pending.items() if k not in kinds}
+            if "vm" in kinds and "lgkm" in kinds:
+                self.stores_waited = True
         # ---- scalar memory
         elif op in ("s_buffer_load_dwordx4", "s_buffer_load_dwordx8"):
             n = 4 if op.endswith("x4") else 8
@@ -396,6 +410,7 @@ class Lane:
                     self.pending[r] = "lgkm"
                 else:
                     self.lds[addr + 4 * k] = self.vread(r)
+                    self.stores_waited = False
         # ---- vector memory
         elif op in ("buffer_load_dwordx4", "buffer_load_dword", "buffer_store_dwordx4", "buffer_store_dword"):
             n = 4 if op.endswith("x4") else 1
@@ -414,6 +429,7 @@ class Lane:
                     self.pending[r] = "vm"
             else:
                 self.mem.store(addr, [self.vread(r) for r in regs])
+                self.stores_waited = False
         else:
             raise ModelError("instruction not modelled: %s %s" % (op, ", ".join(a)))
         return nxt

@@ -30,7 +30,7 @@ IN_BASE, OUT_BASE, LDS_BASE = 0x7E0000000400, 0x7D0000000800, 16
 
 
 def run_lane(ops, consts, inputs, n_outputs, n_lslots, n_gslots, vec, wave=0, lane=0, live=True, want_outputs=True,
-             block=3, victim=True):
+             block=3, victim=True, n_xslots=0):
     """inputs: list over vectors of lists of ints.  Returns (outputs list or None, unsat, first, Lane)."""
     n_vec = len(inputs)
     n_inputs = len(inputs[0]) if inputs else 0
@@ -63,8 +63,9 @@ def run_lane(ops, consts, inputs, n_outputs, n_lslots, n_gslots, vec, wave=0, la
         "%[in_base]": IN_BASE, "%[out_base]": OUT_BASE if want_outputs else 0,
         "%[n4]": 4 * n_vec, "%[live]": (0x8000000000000001 | bit) if live else (0x8000000000000001 & ~bit),
         "%[v_lo]": wave * 2048 + lane * 16, "%[v_vec4]": 4 * v,
+        "%[xbase]": LDS_BASE + (n_lslots + (1 if victim else 0)) * 8192, "%[v_x]": lane * 16,
     }
-    ln = IM.Lane(mem, LDS_BASE + (n_lslots + (1 if victim else 0)) * 8192, lane, operands, set(range(G.VB, G.V_LAST + 1)),
+    ln = IM.Lane(mem, LDS_BASE + (n_lslots + (1 if victim else 0)) * 8192 + n_xslots * 2048, lane, operands, set(range(G.VB, G.V_LAST + 1)),
                  set(range(G.SB, G.S_LAST + 1)), result_operands=("%[unsat]", "%[first]"))
     ln.run(PROG, LABELS)
     outs = None

@@ -1,0 +1,128 @@
+"""Strand tapes: four op streams of one circuit, run side by side by the four wavefronts of a
+workgroup on the same 64 vectors, meeting in exchange slots across barriers
+(include/zkir_hip.h, "Strand tapes").  CPU tests cover the format, the checkers and the
+lowering; the gpu tests compare the kernel with the C checker bit for bit."""
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import zkir_amd as z
+from oracle import c_oracle as C
+from oracle import fr_ref as F
+from zkir_amd import api
+
+G = lambda i: F.operand(F.K_GSLOT, i)  # noqa: E731
+L = lambda i: F.operand(F.K_LSLOT, i)  # noqa: E731
+K = lambda i: F.operand(F.K_CONST, i)  # noqa: E731
+I = lambda i: F.operand(F.K_INPUT, i)  # noqa: E731
+X = lambda i: F.operand(F.K_XSLOT, i)  # noqa: E731
+ACC, NONE = F.operand(F.K_ACC), F.operand(F.K_NONE)
+CHECK = lambda k: F.OP_CHECK | ((k + 1) << 8)  # noqa: E731
+BAR = (F.OP_BARRIER, NONE, NONE, NONE)
+
+
+def strand_tape(strands, consts, n_inputs, n_outputs, n_g, n_l, n_x):
+    ops = [o for s in strands for o in s]
+    checks = sorted((o[0] >> 8, o) for o in ops if o[0] & 0xFF == F.OP_CHECK)
+    hdr = api.TapeHdr(0x31544B5A, 1, n_inputs, n_outputs, len(consts), len(ops), n_g, n_l, len(checks), 0, 1,
+                      (ctypes_u32x4(*[len(s) for s in strands])), n_x)
+    blob = b"".join(struct.pack("<4I", *o) for o in ops) + b"".join(struct.pack("<8I", *F.limbs32(c)) for c in consts)
+    blob += b"".join(struct.pack("<3I", o[2], o[3], o[1]) for _, o in checks)
+    return hdr, blob
+
+
+def ctypes_u32x4(a, b, c, d):
+    import ctypes
+    return (ctypes.c_uint32 * 4)(a, b, c, d)
+
+
+def hand_strands(bad_check=False):
+    """in0, in1 -> out0 = in0*in1, out1 = in0+in1, out2 = (in0-in1)^2, out3 = 7*out0; three constraints."""
+    s0 = [(F.OP_INPUT, X(0), I(0), NONE), BAR,
+          (F.OP_MUL, X(2), X(0), X(1)), (F.OP_OUTPUT, 0, ACC, NONE), (CHECK(0), ACC, X(0), X(1)), BAR]
+    s1 = [(F.OP_INPUT, X(1), I(1), NONE), BAR,
+          (F.OP_ADD, NONE, X(0), X(1)), (F.OP_OUTPUT, 1, ACC, NONE), BAR]
+    s2 = [BAR, (F.OP_SUB, G(0), X(0), X(1)), (F.OP_MUL, L(0), ACC, ACC), (F.OP_OUTPUT, 2, L(0), NONE),
+          (CHECK(1), L(0), G(0), G(0)), BAR]
+    s3 = [BAR, BAR, (F.OP_MUL, NONE, X(2), K(0)), (F.OP_OUTPUT, 3, ACC, NONE),
+          (CHECK(2), X(0) if bad_check else ACC, X(2), K(0))]
+    return strand_tape([s0, s1, s2, s3], [7], 2, 4, 1, 1, 3)
+
+
+def test_checkers_agree_on_a_hand_written_strand_tape():
+    rnd = random.Random(5)
+    hdr, blob = hand_strands()
+    ops = [struct.unpack_from("<4I", blob, 16 * i) for i in range(hdr.n_ops)]
+    vecs = [[rnd.randrange(F.P) for _ in range(2)] for _ in range(9)] + [[0, 0], [F.P - 1, 1]]
+    inp = z.pack_inputs(vecs, 2)
+    out, unsat, first, faults = C.eval_cpu(bytes(hdr), blob, inp, len(vecs), 4)
+    got = z.unpack_outputs(out)
+    for t, (a, b) in enumerate(vecs):
+        want = [a * b % F.P, (a + b) % F.P, (a - b) ** 2 % F.P, 7 * a * b % F.P]
+        assert got[t] == want
+        o_py, u_py, f_py = F.eval_tape_one(ops, [7], [a, b], strand_ops=list(hdr.strand_ops))
+        assert [o_py[k] for k in range(4)] == want and u_py == [] and f_py == 0
+    assert (unsat, first, faults) == (0, None, 0)
+    # a constraint that does not hold is reported under the number its CHECK op carries
+    hdr, blob = hand_strands(bad_check=True)
+    ops = [struct.unpack_from("<4I", blob, 16 * i) for i in range(hdr.n_ops)]
+    out, unsat, first, faults = C.eval_cpu(bytes(hdr), blob, inp, len(vecs), 4)
+    bad = [t for t, (a, b) in enumerate(vecs) if 7 * a * b % F.P != a]
+    assert unsat == len(bad) and first == (bad[0], 2)
+    assert F.eval_tape_one(ops, [7], vecs[bad[0]], strand_ops=list(hdr.strand_ops))[1] == [2]
+
+
+def test_validation_of_strand_tapes():
+    hdr, blob = hand_strands()
+    z.Tape.from_parts(hdr, blob)  # well formed
+    ops = [list(struct.unpack_from("<4I", blob, 16 * i)) for i in range(hdr.n_ops)]
+    tail = blob[16 * hdr.n_ops:]
+
+    def rebuilt(ops2, **hdr_changes):
+        h = api.TapeHdr.from_buffer_copy(bytes(hdr))
+        for k, v in hdr_changes.items():
+            setattr(h, k, v)
+        return h, b"".join(struct.pack("<4I", *o) for o in ops2) + tail
+
+    cases = []
+    o2 = [list(o) for o in ops]
+    o2[1] = [F.OP_NOP, NONE, NONE, NONE]  # strand 0 loses a barrier: the wavefronts would wait forever
+    cases.append(rebuilt(o2))
+    o2 = [list(o) for o in ops]
+    o2[2][1] = X(3)  # exchange slot beyond n_xslots
+    cases.append(rebuilt(o2))
+    o2 = [list(o) for o in ops]
+    o2[4][0] = F.OP_CHECK  # no constraint number
+    cases.append(rebuilt(o2))
+    o2 = [list(o) for o in ops]
+    o2[4][0] = CHECK(1)  # number used twice
+    cases.append(rebuilt(o2))
+    cases.append(rebuilt(ops, strand_ops=ctypes_u32x4(6, 5, 6, 4)))  # counts do not add up
+    cases.append(rebuilt(ops, flags=0))  # strand fields / exchange operands on a plain tape
+    cases.append(rebuilt(ops, n_xslots=33))
+    for h, b in cases:
+        with pytest.raises(z.ZkirError):
+            z.Tape.from_parts(h, b)
+
+
+@pytest.mark.gpu
+def test_hand_written_strand_tape_on_the_gpu():
+    rnd = random.Random(6)
+    ctx = z.Context(0)
+    try:
+        for bad, n in ((False, 1), (False, 64), (False, 65), (True, 200), (False, 1000)):
+            hdr, blob = hand_strands(bad_check=bad)
+            tape = z.Tape.from_parts(hdr, blob)
+            vecs = [[rnd.randrange(F.P) for _ in range(2)] for _ in range(n)]
+            inp = z.pack_inputs(vecs, 2)
+            tid = ctx.upload(tape)
+            out, unsat, first, faults = ctx.eval_batch(tid, inp, n)
+            ctx.release(tid)
+            o_c, u_c, first_c, f_c = C.eval_cpu(bytes(hdr), blob, inp, n, 4)
+            assert np.array_equal(out, o_c)
+            assert (unsat, first, faults) == (u_c, first_c, f_c)
+            assert (unsat > 0) == bad
+    finally:
+        ctx.close()

@@ -24,6 +24,14 @@ Slot layout (both LDS window and device slots): slot s occupies 8 KiB;
   byte(s, wave, plane, lane) = s*8192 + wave*2048 + plane*1024 + lane*16
 plane 0 holds limbs 0..3, plane 1 limbs 4..7, so a wave reads or writes a plane as one
 1 KiB row.
+
+Strand tapes (four wavefronts of a workgroup run four op streams on the same 64 vectors): the
+stream is the same; a wavefront reads its own strand's ops, keeps its own rows of every slot
+(the wave term of the layout above), and meets the others in exchange slots of 2 KiB,
+  byte(x, plane, lane) = xbase + x*2048 + plane*1024 + lane*16       (LDS, operand kind 6)
+which are never remembered in the operand tags, and at BARRIER ops (all memory operations
+waited for, then s_barrier).  A CHECK op of such a tape carries its constraint number + 1 in
+bits 8..31 of its code word; 0 there means "count the checks" (plain tapes).
 """
 import os
 import sys
@@ -78,8 +86,8 @@ TAG_V = "s%d" % (SB + 41)  # device-slot operand word whose value sits in the vi
 S_LAST = SB + 51
 assert S_LAST <= 99  # s100 and above are reserved by the compiler on this target
 
-K_GSLOT, K_LSLOT, K_CONST, K_INPUT, K_ACC, K_NONE = 0, 1, 2, 3, 4, 5
-OP_INPUT, OP_OUTPUT, OP_COPY, OP_NEG, OP_ADD, OP_SUB, OP_MUL, OP_CHECK = 1, 2, 3, 4, 16, 17, 18, 48
+K_GSLOT, K_LSLOT, K_CONST, K_INPUT, K_ACC, K_NONE, K_XSLOT = 0, 1, 2, 3, 4, 5, 6
+OP_INPUT, OP_OUTPUT, OP_COPY, OP_NEG, OP_BARRIER, OP_ADD, OP_SUB, OP_MUL, OP_CHECK = 1, 2, 3, 4, 7, 16, 17, 18, 48
 
 # operands of the asm statement (all inputs are read-only)
 IN_OPS, IN_NOPS, IN_CST, IN_NCST = "%[ops]", "%[n_ops]", "%[consts]", "%[n_consts]"
@@ -88,6 +96,7 @@ IN_INB, IN_OUTB = "%[in_base]", "%[out_base]"
 IN_N4, IN_LIVE = "%[n4]", "%[live]"
 IN_VLO, IN_VVEC = "%[v_lo]", "%[v_vec4]"
 IN_EVICT = "%[evict_below]"  # 0x20000000 when the launch has a victim row, 0 when it has none
+IN_XBASE, IN_VX = "%[xbase]", "%[v_x]"  # strand tapes: LDS address of the exchange slots, lane * 16
 OUT_UNSAT, OUT_FIRST = "%[unsat]", "%[first]"
 
 
@@ -218,7 +227,7 @@ def fetch(a, sop, dst_base, addr, acc_label=None, stem="f", tag=None):
     and nothing is loaded."""
     dst = vreg8(dst_base)
     l_lds, l_glb, l_cst, l_done = a.new(stem + "lds"), a.new(stem + "glb"), a.new(stem + "cst"), a.new(stem + "done")
-    l_vhit, l_noev = a.new(stem + "vhit"), a.new(stem + "noev")
+    l_vhit, l_noev, l_x = a.new(stem + "vhit"), a.new(stem + "noev"), a.new(stem + "x")
     if tag:
         a.e("s_cmp_eq_u32 %s, %s" % (sop, tag))
         a.e("s_cbranch_scc1 %s" % l_done)
@@ -250,6 +259,8 @@ def fetch(a, sop, dst_base, addr, acc_label=None, stem="f", tag=None):
     a.e("s_cbranch_scc1 %s" % l_glb)
     a.e("s_cmp_eq_u32 %s, %d" % (T0, K_CONST))
     a.e("s_cbranch_scc1 %s" % l_cst)
+    a.e("s_cmp_eq_u32 %s, %d" % (T0, K_XSLOT))
+    a.e("s_cbranch_scc1 %s" % l_x)
     # any other kind reads as zero (the host validates tapes; this keeps the stream total)
     for j in range(8):
         a.e("v_mov_b32 %s, 0" % dst[j])
@@ -264,6 +275,15 @@ def fetch(a, sop, dst_base, addr, acc_label=None, stem="f", tag=None):
             if tag:
                 a.e("s_mov_b32 %s, -1" % tag)
         a.e("s_branch %s" % l_done)
+    a.label(l_x)  # exchange slot: another wavefront may rewrite it, so the tag forgets it
+    if tag:
+        a.e("s_mov_b32 %s, -1" % tag)
+    a.e("s_lshl_b32 %s, %s, 11" % (T1, T1))
+    a.e("s_add_u32 %s, %s, %s" % (T1, T1, IN_XBASE))
+    a.e("v_add_u32 %s, %s, %s" % (addr, T1, IN_VX))
+    a.e("ds_read_b128 %s, %s" % (quad(dst_base, 0), addr))
+    a.e("ds_read_b128 %s, %s offset:1024" % (quad(dst_base, 1), addr))
+    a.e("s_branch %s" % l_done)
     a.label(l_cst)
     if tag:
         a.e("s_mov_b32 %s, %s" % (tag, sop))
@@ -442,7 +462,13 @@ def build():
     a.e("s_bcnt1_i32_b64 %s, %s" % (T0, CC2))
     a.e("s_add_u32 %s, %s, %s" % (UNSAT_LO, UNSAT_LO, T0))
     a.e("s_addc_u32 %s, %s, 0" % (UNSAT_HI, UNSAT_HI))
-    a.e("v_mov_b32 %s, %s" % (VT0, KCHK))
+    # the constraint number: carried by the op (number + 1 in bits 8..31) or, when that is 0, the count so far
+    a.e("s_lshr_b32 %s, %s, 8" % (T1, OP[0]))
+    a.e("s_cbranch_scc1 .Lzk_cmp_id")
+    a.e("s_add_u32 %s, %s, 1" % (T1, KCHK))
+    a.label(".Lzk_cmp_id")
+    a.e("s_sub_u32 %s, %s, 1" % (T1, T1))
+    a.e("v_mov_b32 %s, %s" % (VT0, T1))
     a.e("v_mov_b32 %s, -1" % VT1)
     a.e("v_cndmask_b32_e64 %s, %s, %s, %s" % (VT0, VT1, VT0, CC2))
     a.e("v_min_u32 %s, %s, %s" % (FIRST, FIRST, VT0))
@@ -460,7 +486,13 @@ def build():
     a.e("s_cbranch_scc1 .Lzk_copy")
     a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_NEG))
     a.e("s_cbranch_scc1 .Lzk_neg")
-    a.e("s_branch .Lzk_next")  # NOP and anything unknown
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_BARRIER))
+    a.e("s_cbranch_scc0 .Lzk_next")  # NOP and anything unknown
+    # BARRIER: everything this wavefront stored is visible to the workgroup once its memory
+    # operations have completed; then wait for the other strands
+    a.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    a.e("s_barrier")
+    a.e("s_branch .Lzk_next")
 
     def io_descriptor(base, index_reg):
         # element `index` of the tape's inputs (outputs): 8 limb rows of n vectors, 32*n bytes
@@ -538,6 +570,8 @@ def build():
     a.e("s_lshl_b32 %s, %s, 13" % (T1, T1))
     a.e("s_cmp_eq_u32 %s, %d" % (T0, K_LSLOT))
     a.e("s_cbranch_scc1 .Lzk_st_lds")
+    a.e("s_cmp_eq_u32 %s, %d" % (T0, K_XSLOT))
+    a.e("s_cbranch_scc1 .Lzk_st_x")
     a.e("s_cmp_eq_u32 %s, %d" % (T0, K_GSLOT))
     a.e("s_cbranch_scc0 .Lzk_next")
     a.e("v_add_u32 %s, %s, %s" % (AD_C, T1, IN_VLO))
@@ -548,6 +582,13 @@ def build():
     a.label(".Lzk_st_lds")
     a.e("s_add_u32 %s, %s, %s" % (T1, T1, IN_LDSB))
     a.e("v_add_u32 %s, %s, %s" % (AD_C, T1, IN_VLO))
+    a.e("ds_write_b128 %s, %s" % (AD_C, quad(VACC, 0)))
+    a.e("ds_write_b128 %s, %s offset:1024" % (AD_C, quad(VACC, 1)))
+    a.e("s_branch .Lzk_next")
+    a.label(".Lzk_st_x")
+    a.e("s_lshr_b32 %s, %s, 2" % (T1, T1))  # index << 13 -> index << 11
+    a.e("s_add_u32 %s, %s, %s" % (T1, T1, IN_XBASE))
+    a.e("v_add_u32 %s, %s, %s" % (AD_C, T1, IN_VX))
     a.e("ds_write_b128 %s, %s" % (AD_C, quad(VACC, 0)))
     a.e("ds_write_b128 %s, %s offset:1024" % (AD_C, quad(VACC, 1)))
     a.label(".Lzk_next")

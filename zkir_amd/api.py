@@ -36,7 +36,7 @@ class LowerRejected(ZkirError):
 
 class TapeHdr(ctypes.Structure):
     _fields_ = [(n, c_uint32) for n in ("magic", "version", "n_inputs", "n_outputs", "n_consts", "n_ops", "n_gslots",
-                                        "n_lslots", "n_constraints", "n_mul_ops", "flags")] + [("reserved", c_uint32 * 5)]
+                                        "n_lslots", "n_constraints", "n_mul_ops", "flags")] + [("strand_ops", c_uint32 * 4), ("n_xslots", c_uint32)]
 
 
 class GeneratorConfig(ctypes.Structure):

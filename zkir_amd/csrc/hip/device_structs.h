@@ -8,7 +8,7 @@
 
 namespace zkir {
 
-// Device-side description of one uploaded tape (64 bytes, read with scalar loads).
+// Device-side description of one uploaded tape (96 bytes, read with scalar loads).
 struct TapeDesc {
   const zkir_op* ops;      // n_ops entries
   const uint32_t* consts;  // n_consts x 8 limbs, Montgomery form
@@ -19,8 +19,11 @@ struct TapeDesc {
   uint32_t n_outputs;
   uint32_t n_constraints;
   uint32_t n_consts;
-  uint32_t reserved[3];
+  uint32_t n_xslots;       // strand tapes: exchange slots
+  uint32_t reserved[2];
+  uint32_t strand_begin[ZKIR_STRANDS];  // strand tapes: first op of each strand
+  uint32_t strand_ops[ZKIR_STRANDS];    // strand tapes: ops of each strand
 };
-static_assert(sizeof(TapeDesc) == 64, "TapeDesc must stay 64 bytes");
+static_assert(sizeof(TapeDesc) == 96, "TapeDesc is read as 96 bytes");
 
 }  // namespace zkir

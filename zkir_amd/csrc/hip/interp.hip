@@ -351,20 +351,27 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
 // Limits the host checks before choosing this kernel: 32 * n_vectors < 2^32.
 #include "interp_core_asm.inc"
 
+// strands != 0: every tape of the launch is a strand tape.  The four wavefronts of a workgroup
+// then run the four op streams of the tape on the SAME 64 vectors (a pass is 64 vectors, not
+// 256), each with its own rows of the slots, and meet in the exchange slots that follow the
+// `lslots` window slots in LDS.  The tape's barriers pair up across the wavefronts because the
+// host only uploads strand tapes whose strands hold the same number of them.
 __global__ void __launch_bounds__(kBlock, 2)
 zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_t passes_per_tape,
                         uint64_t n_vectors, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ outputs,
                         uint4* __restrict__ gslot_pool, uint32_t gslots_per_block,
                         uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats,
-                        uint32_t* __restrict__ work_counter, uint32_t victim_row) {
+                        uint32_t* __restrict__ work_counter, uint32_t victim_row, uint32_t strands, uint32_t lslots) {
   __shared__ uint32_t next_item;
   const uint64_t gslots = (uint64_t)(uintptr_t)(gslot_pool + (size_t)blockIdx.x * gslots_per_block * 2 * kBlock);
   const uint32_t gslot_bytes = gslots_per_block * (uint32_t)(2 * kBlock * sizeof(uint4));
   // the low half of a generic pointer into LDS is the LDS byte address; with a victim row the
   // first 8 KiB of the dynamic allocation are that row and the window slots follow
   const uint32_t lds_base = (uint32_t)(uintptr_t)zkir_lds_slots + (victim_row ? 8192u : 0u);
+  const uint32_t xbase = lds_base + lslots * 8192u;
   const uint32_t evict_below = victim_row ? 0x20000000u : 0u;
-  const uint32_t v_lo = (threadIdx.x >> 6) * 2048u + (threadIdx.x & 63u) * 16u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const uint32_t v_lo = wave * 2048u + lane * 16u, v_x = lane * 16u;
   const uint32_t n4 = (uint32_t)n_vectors * 4u;
 
   const uint64_t total = (uint64_t)n_tapes * passes_per_tape;
@@ -376,12 +383,16 @@ zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, ui
     if (w >= total) break;
     const uint32_t tape_i = (uint32_t)(w / passes_per_tape);
     const uint32_t pass = (uint32_t)(w % passes_per_tape);
-    const TapeDesc td = ((uniform_desc_t)tapes)[tape_i];
-    const uint64_t vec = (uint64_t)pass * kBlock + threadIdx.x;
+    uniform_desc_t tdp = (uniform_desc_t)tapes + tape_i;
+    const TapeDesc td = *tdp;
+    const uint64_t vec = strands ? (uint64_t)pass * 64u + lane : (uint64_t)pass * kBlock + threadIdx.x;
     const bool live = vec < n_vectors;
     const uint32_t v_vec4 = live ? (uint32_t)vec * 4u : 0u;  // idle lanes recompute vector 0 and report nothing
     const uint64_t live_mask = __ballot(live);
-    const uint64_t ops = (uint64_t)(uintptr_t)td.ops, consts = (uint64_t)(uintptr_t)td.consts;
+    // indexed through the pointer, not the copy: a run-time index into `td` would move it to scratch
+    const uint32_t first_op = strands ? tdp->strand_begin[wave] : 0u;
+    const uint32_t n_ops = strands ? tdp->strand_ops[wave] : td.n_ops;
+    const uint64_t ops = (uint64_t)(uintptr_t)(td.ops + first_op), consts = (uint64_t)(uintptr_t)td.consts;
     const uint64_t in_base = (uint64_t)(uintptr_t)(inputs + td.in_word_off);
     const uint64_t out_base = outputs ? (uint64_t)(uintptr_t)(outputs + td.out_word_off) : 0;  // 0: not wanted
 
@@ -389,12 +400,13 @@ zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, ui
     uint32_t first_bad;
     asm volatile(ZKIR_INTERP_CORE_ASM
                  : [unsat] "=s"(wave_unsat), [first] "=v"(first_bad)
-                 : [ops] "s"(ops), [n_ops] "s"(td.n_ops), [consts] "s"(consts), [n_consts] "s"(td.n_consts),
+                 : [ops] "s"(ops), [n_ops] "s"(n_ops), [consts] "s"(consts), [n_consts] "s"(td.n_consts),
                    [gslots] "s"(gslots), [gslot_bytes] "s"(gslot_bytes), [lds_base] "s"(lds_base),
-                   [in_base] "s"(in_base), [out_base] "s"(out_base), [n4] "s"(n4), [live] "s"(live_mask), [evict_below] "s"(evict_below), [v_lo] "v"(v_lo), [v_vec4] "v"(v_vec4)
+                   [in_base] "s"(in_base), [out_base] "s"(out_base), [n4] "s"(n4), [live] "s"(live_mask),
+                   [evict_below] "s"(evict_below), [xbase] "s"(xbase), [v_lo] "v"(v_lo), [v_vec4] "v"(v_vec4), [v_x] "v"(v_x)
                  : ZKIR_INTERP_CORE_CLOBBERS);
 
-    if ((threadIdx.x & 63) == 0 && wave_unsat)
+    if (lane == 0 && wave_unsat)
       atomicAdd((unsigned long long*)&unsat_per_tape[tape_i], (unsigned long long)wave_unsat);
     if (live && first_bad != 0xffffffffu)
       atomicMin((unsigned long long*)&stats[0], (unsigned long long)((vec << 32) | first_bad));
@@ -478,36 +490,40 @@ static const void* interp_entry(int variant) {
 
 // The generated stream parks evicted operands in one extra 8 KiB row of LDS when that row does
 // not cost a resident workgroup (five fit a CU up to 32 KiB each).
-static bool interp_victim_row(int variant, uint32_t lslots) {
+static bool interp_victim_row(int variant, uint32_t lslots, uint32_t strands) {
   static const bool off = std::getenv("ZKIR_NO_VICTIM_ROW") != nullptr;  // measurement aid
-  return variant == 2 && lslots + 1 <= 4 && !off;
+  return variant == 2 && !strands && lslots + 1 <= 4 && !off;
 }
-// dynamic LDS of a workgroup: the window slots, plus the victim row
-static size_t interp_lds_bytes(int variant, uint32_t lslots) {
-  return (size_t)(lslots + (interp_victim_row(variant, lslots) ? 1 : 0)) * 2 * kBlock * sizeof(uint4);
+// dynamic LDS of a workgroup: the window slots, plus the victim row, plus (strand tapes) the
+// exchange slots of 64 lanes x 32 bytes
+static size_t interp_lds_bytes(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots) {
+  return (size_t)(lslots + (interp_victim_row(variant, lslots, strands) ? 1 : 0)) * 2 * kBlock * sizeof(uint4) +
+         (strands ? (size_t)xslots * 2048 : 0);
 }
 
 hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
-                         uint32_t* work_counter, uint32_t grid, hipStream_t stream) {
-  const size_t lds_bytes = interp_lds_bytes(variant, lslots);
+                         uint32_t* work_counter, uint32_t grid, uint32_t strands, uint32_t xslots, hipStream_t stream) {
+  const size_t lds_bytes = interp_lds_bytes(variant, lslots, strands, xslots);
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (variant == 2 && n_vectors * 32 >= (1ull << 32)) return hipErrorInvalidValue;
+  if (strands && variant != 2) return hipErrorInvalidValue;  // only the generated stream knows strand tapes
   if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS limit the kernel must opt in
     hipError_t e = hipFuncSetAttribute(interp_entry(variant), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
   uint4* pool = (uint4*)gslot_pool;
-  uint32_t victim_row = interp_victim_row(variant, lslots) ? 1u : 0u;  // read by the generated-stream kernel only
+  // the last three are read by the generated-stream kernel only
+  uint32_t victim_row = interp_victim_row(variant, lslots, strands) ? 1u : 0u;
   void* args[] = {&tapes_dev, &n_tapes, &passes_per_tape, &n_vectors, &inputs, &outputs, &pool, &gslots_per_block,
-                  &unsat_per_tape, &stats, &work_counter, &victim_row};
+                  &unsat_per_tape, &stats, &work_counter, &victim_row, &strands, &lslots};
   return hipLaunchKernel(interp_entry(variant), dim3(grid), dim3(kBlock), args, lds_bytes, stream);
 }
 
 // workgroups of the interpreter that fit on one CU with `lslots` window slots
-hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, int* blocks) {
-  const size_t lds_bytes = interp_lds_bytes(variant, lslots);
+hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots, int* blocks) {
+  const size_t lds_bytes = interp_lds_bytes(variant, lslots, strands, xslots);
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, interp_entry(variant), kBlock, lds_bytes);
   if (e == hipSuccess && *blocks < 1) *blocks = 1;
   return e;

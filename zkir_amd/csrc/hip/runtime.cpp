@@ -20,8 +20,8 @@ namespace zkir {
 hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
-                         uint32_t* work_counter, uint32_t grid, hipStream_t stream);
-hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, int* blocks);
+                         uint32_t* work_counter, uint32_t grid, uint32_t strands, uint32_t xslots, hipStream_t stream);
+hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots, int* blocks);
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream);
 hipError_t launch_int_mul_rate(int which, uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
 hipError_t launch_fr_mul_rate(uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
@@ -129,9 +129,10 @@ int32_t arena_alloc(zkir_ctx* ctx, size_t bytes, void** out, int* slab_out) {
   return ZKIR_OK;
 }
 
-uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, int variant, uint32_t lslots) {
+uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, int variant, uint32_t lslots, uint32_t strands,
+                   uint32_t xslots) {
   int per_cu = 2;
-  if (zkir::interp_blocks_per_cu(variant, lslots, &per_cu) != hipSuccess) per_cu = 2;
+  if (zkir::interp_blocks_per_cu(variant, lslots, strands, xslots, &per_cu) != hipSuccess) per_cu = 2;
   if (const char* cap = std::getenv("ZKIR_BLOCKS_PER_CU"))  // measurement aid: fewer resident workgroups
     per_cu = std::max(1, std::min(per_cu, std::atoi(cap)));
   const uint64_t g = (uint64_t)ctx->n_cu * (uint64_t)per_cu;
@@ -152,7 +153,8 @@ int pick_variant(bool full, uint64_t N) {
 struct Launch {
   std::vector<TapeDesc> descs;
   bool full = false;
-  uint32_t max_gslots = 0, max_lslots = 0;
+  uint32_t n_strand_tapes = 0;  // a launch is all strand tapes or none
+  uint32_t max_gslots = 0, max_lslots = 0, max_xslots = 0;
 };
 
 int32_t build_launch(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, uint64_t N, Launch* L) {
@@ -173,6 +175,17 @@ int32_t build_launch(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, uint64_
     d.n_outputs = t.hdr.n_outputs;
     d.n_constraints = t.hdr.n_constraints;
     d.n_consts = t.hdr.n_consts;
+    if (t.hdr.flags & ZKIR_TAPE_F_STRANDS) {
+      L->n_strand_tapes++;
+      d.n_xslots = t.hdr.n_xslots;
+      uint32_t begin = 0;
+      for (uint32_t s = 0; s < ZKIR_STRANDS; s++) {
+        d.strand_begin[s] = begin;
+        d.strand_ops[s] = t.hdr.strand_ops[s];
+        begin += t.hdr.strand_ops[s];
+      }
+      L->max_xslots = std::max(L->max_xslots, t.hdr.n_xslots);
+    }
     in_off += (uint64_t)t.hdr.n_inputs * 8 * N;
     out_off += (uint64_t)t.hdr.n_outputs * 8 * N;
     L->full = L->full || t.full;
@@ -191,11 +204,20 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
   Launch L;
   int32_t rc = build_launch(ctx, ids, n, N, &L);
   if (rc) return rc;
-  const uint32_t passes = (uint32_t)((N + ZKIR_BLOCK_THREADS - 1) / ZKIR_BLOCK_THREADS);
+  if (L.n_strand_tapes && L.n_strand_tapes != n)
+    return fail(ctx, ZKIR_E_INVALID, "a launch takes strand tapes or plain tapes, not both");
+  const uint32_t strands = L.n_strand_tapes ? 1u : 0u;
+  // a pass is one workgroup's worth of vectors: 256, or 64 when its four wavefronts are the four strands
+  const uint32_t per_pass = strands ? 64u : (uint32_t)ZKIR_BLOCK_THREADS;
+  const uint32_t passes = (uint32_t)((N + per_pass - 1) / per_pass);
   const uint64_t work = (uint64_t)n * passes;
   if (work >= (1ull << 32) - (1u << 20)) return fail(ctx, ZKIR_E_LIMIT, "too many (tape, pass) work items for one launch");
-  const int variant = pick_variant(L.full, N);
-  const uint32_t grid = pick_grid(ctx, work, variant, L.max_lslots);
+  int variant = pick_variant(L.full, N);
+  if (strands) {  // only the generated stream runs strand tapes (upload refused any other operator)
+    if (N * 32 >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 2^27 vectors per launch");
+    variant = 2;
+  }
+  const uint32_t grid = pick_grid(ctx, work, variant, L.max_lslots, strands, L.max_xslots);
   const size_t slot_bytes = (size_t)2 * ZKIR_BLOCK_THREADS * 16;
   rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, (size_t)grid * L.max_gslots * slot_bytes);
   if (rc) return rc;
@@ -211,7 +233,7 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
   HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, 256, stream));
   hipError_t e = zkir::launch_interp(variant, (const TapeDesc*)ctx->desc_buf, n, passes, N, in_dev, out_dev, ctx->gslot_pool,
                                      L.max_gslots, L.max_lslots, unsat_dev, stats_dev, (uint32_t*)ctx->work_counter,
-                                     grid, stream);
+                                     grid, strands, L.max_xslots, stream);
   if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
   return ZKIR_OK;
 }
@@ -268,9 +290,11 @@ int32_t zkir_tape_upload(zkir_ctx* ctx, const zkir_tape_hdr* hdr, const void* bl
   DevTape t;
   t.hdr = *hdr;
   for (uint32_t i = 0; i < hdr->n_ops; i++) {
-    const uint32_t c = ((const zkir_op*)blob)[i].code;
+    const uint32_t c = ((const zkir_op*)blob)[i].code & 0xffu;
     if (c == ZKIR_OP_BNOT || c == ZKIR_OP_BNOT256 || (c >= ZKIR_OP_POW && c <= ZKIR_OP_SHL)) t.full = true;
   }
+  if (t.full && (hdr->flags & ZKIR_TAPE_F_STRANDS))
+    return fail(ctx, ZKIR_E_INVALID, "bad tape: strand tapes are made of + - * and data movement only");
   // ops and constants are adjacent in the blob and stay adjacent on the device: one copy
   const size_t ops_bytes = (size_t)hdr->n_ops * sizeof(zkir_op);
   const size_t consts_bytes = (size_t)hdr->n_consts * 32;

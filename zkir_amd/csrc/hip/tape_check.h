@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../../include/zkir_hip.h"
 
@@ -17,6 +18,7 @@ inline bool check_source(const zkir_tape_hdr& h, uint32_t o, std::string* why) {
     case ZKIR_KIND_LSLOT: if (idx < h.n_lslots) return true; break;
     case ZKIR_KIND_CONST: if (idx < h.n_consts) return true; break;
     case ZKIR_KIND_ACC: return true;
+    case ZKIR_KIND_XSLOT: if ((h.flags & ZKIR_TAPE_F_STRANDS) && idx < h.n_xslots) return true; break;
     default: break;
   }
   if (why) *why = "source operand out of range";
@@ -28,6 +30,7 @@ inline bool check_dest(const zkir_tape_hdr& h, uint32_t o, std::string* why) {
   if (kind == ZKIR_KIND_NONE) return true;
   if (kind == ZKIR_KIND_GSLOT && idx < h.n_gslots) return true;
   if (kind == ZKIR_KIND_LSLOT && idx < h.n_lslots) return true;
+  if (kind == ZKIR_KIND_XSLOT && (h.flags & ZKIR_TAPE_F_STRANDS) && idx < h.n_xslots) return true;
   if (why) *why = "destination operand out of range";
   return false;
 }
@@ -39,6 +42,16 @@ inline bool check_tape(const zkir_tape_hdr& h, const void* blob, size_t bytes, s
   };
   if (h.magic != ZKIR_TAPE_MAGIC || h.version != ZKIR_TAPE_VERSION) return bad("magic/version");
   if (h.n_lslots > ZKIR_MAX_LSLOTS) return bad("too many on-chip slots");
+  if (h.flags & ~ZKIR_TAPE_F_STRANDS) return bad("unknown flag bits");
+  const bool strands = (h.flags & ZKIR_TAPE_F_STRANDS) != 0;
+  if (strands) {
+    uint64_t sum = 0;
+    for (uint32_t s = 0; s < ZKIR_STRANDS; s++) sum += h.strand_ops[s];
+    if (sum != h.n_ops) return bad("strand op counts do not add up to n_ops");
+    if (h.n_xslots > ZKIR_MAX_XSLOTS) return bad("too many exchange slots");
+  } else if (h.strand_ops[0] | h.strand_ops[1] | h.strand_ops[2] | h.strand_ops[3] | h.n_xslots) {
+    return bad("strand fields set on a plain tape");
+  }
   if (h.n_ops > (1u << 26) || h.n_consts > (1u << 26) || h.n_gslots > (1u << 24) || h.n_inputs > (1u << 24) ||
       h.n_outputs > (1u << 24))
     return bad("table size beyond limit");
@@ -47,11 +60,30 @@ inline bool check_tape(const zkir_tape_hdr& h, const void* blob, size_t bytes, s
   if (need && !blob) return bad("null blob");
   const zkir_op* ops = (const zkir_op*)blob;
   uint32_t checks = 0;
+  // strand tapes: barriers per strand (all strands must hold the same number, or the
+  // wavefronts of a workgroup would wait for each other forever), and every constraint
+  // number exactly once
+  uint32_t barriers[ZKIR_STRANDS] = {0, 0, 0, 0};
+  uint32_t strand = 0, strand_end = strands ? h.strand_ops[0] : h.n_ops;
+  std::vector<bool> seen_check(strands ? h.n_constraints : 0, false);
   for (uint32_t i = 0; i < h.n_ops; i++) {
     const zkir_op& op = ops[i];
-    if (op.code & ~0xffu) return bad("reserved opcode bits set");
-    const uint32_t code = op.code;
+    while (strands && i >= strand_end && strand + 1 < ZKIR_STRANDS) strand_end += h.strand_ops[++strand];
+    const uint32_t code = op.code & 0xffu;
+    if (op.code & ~0xffu) {
+      if (!(strands && code == ZKIR_OP_CHECK)) return bad("reserved opcode bits set");
+      const uint32_t id = (op.code >> 8) - 1;
+      if (id >= h.n_constraints || seen_check[id]) return bad("constraint number out of range or repeated");
+      seen_check[id] = true;
+    } else if (strands && code == ZKIR_OP_CHECK) {
+      return bad("CHECK op of a strand tape carries no constraint number");
+    }
     if (code == ZKIR_OP_NOP) continue;
+    if (code == ZKIR_OP_BARRIER) {
+      if (!strands) return bad("BARRIER in a plain tape");
+      barriers[strand]++;
+      continue;
+    }
     if (code == ZKIR_OP_INPUT) {
       if ((op.a >> ZKIR_KIND_SHIFT) != ZKIR_KIND_INPUT || (op.a & ZKIR_INDEX_MASK) >= h.n_inputs)
         return bad("input index out of range");
@@ -71,6 +103,8 @@ inline bool check_tape(const zkir_tape_hdr& h, const void* blob, size_t bytes, s
     }
   }
   if (checks != h.n_constraints) return bad("n_constraints does not match the CHECK ops");
+  if (strands && (barriers[1] != barriers[0] || barriers[2] != barriers[0] || barriers[3] != barriers[0]))
+    return bad("strands hold different numbers of barriers");
   return true;
 }
 
