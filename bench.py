@@ -39,7 +39,7 @@ def workload_tape(z, signal_window=0, linear_terms=1):
     g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = 16, 1, 1, 1
     g.no_loops, g.safe_array_index = 1, 1
     o = z.default_lower_options()
-    for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots"):  # experiment knobs
+    for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots", "strands", "max_xslots"):  # experiment knobs
         if os.environ.get("ZKIR_BENCH_" + k.upper()):
             setattr(o, k, int(os.environ["ZKIR_BENCH_" + k.upper()]))
     return z.Lowerer(z.Generator(WORKLOAD_SEED, g).generate(), o).lower()
@@ -48,7 +48,7 @@ def workload_tape(z, signal_window=0, linear_terms=1):
 def gadget_tape(z, rounds=20834):
     """configs[4] of BASELINE.json: Poseidon-style chain, width 4, 3*4*rounds constraints."""
     o = z.default_lower_options()
-    for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots"):
+    for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots", "strands", "max_xslots"):
         if os.environ.get("ZKIR_BENCH_" + k.upper()):
             setattr(o, k, int(os.environ["ZKIR_BENCH_" + k.upper()]))
     return z.Lowerer(z.poseidon_style_gadget(4, rounds, 7), o).lower()

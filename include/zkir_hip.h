@@ -277,6 +277,11 @@ typedef struct zkir_lower_options {
   uint32_t window_lifetime;/* values read for the last time more than this many
                               ops after their definition go to device memory,
                               not the on-chip window (0 = 48)                 */
+  uint32_t strands;        /* 4: cut the ops into four strands (a strand tape, for
+                              batches too small to fill the machine) when the
+                              circuit is made of + - * and its cross-strand values
+                              fit the exchange slots; 0: one op stream          */
+  uint32_t max_xslots;     /* exchange slots a strand tape may use (0 = 32)     */
 } zkir_lower_options;
 
 int32_t zkir_lower_options_default(zkir_lower_options* o);

@@ -126,3 +126,142 @@ def test_hand_written_strand_tape_on_the_gpu():
             assert (unsat > 0) == bad
     finally:
         ctx.close()
+
+
+def _ext_config(n, seed_inputs=6):
+    g = z.default_generator_config()
+    g.min_instructions = g.max_instructions = n
+    g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = seed_inputs, 1, 1, 1
+    g.no_loops, g.safe_array_index = 1, 1
+    return g
+
+
+def _strand_options(**kw):
+    o = z.default_lower_options()
+    o.strands = 4
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _circuits():
+    yield "gadget width 4", z.poseidon_style_gadget(4, 12, 3), 4
+    yield "gadget width 3", z.poseidon_style_gadget(3, 9, 4), 3
+    yield "gadget width 1", z.poseidon_style_gadget(1, 9, 5), 1
+    for seed in range(1, 25):
+        yield "generated %d" % seed, z.Generator(seed, _ext_config(20 + 7 * seed)).generate(), 6
+
+
+def test_lowering_into_strands_keeps_every_result():
+    """The strand tape of a circuit gives, vector for vector, the outputs, the unsatisfied count and
+    the first unsatisfied pair of its plain tape (C checker), and its ops are the plain tape's ops
+    plus barriers."""
+    rnd = random.Random(9)
+    n_strand_tapes = 0
+    for name, circuit, n_in in _circuits():
+        plain = z.Lowerer(circuit).lower()
+        st = z.Lowerer(circuit, _strand_options()).lower()
+        vecs = [[rnd.randrange(F.P) for _ in range(n_in)] for _ in range(11)]
+        inp = z.pack_inputs(vecs, n_in)
+        want = C.eval_cpu(bytes(plain.hdr), plain.blob(), inp, len(vecs), plain.hdr.n_outputs)
+        got = C.eval_cpu(bytes(st.hdr), st.blob(), inp, len(vecs), st.hdr.n_outputs)
+        assert np.array_equal(want[0], got[0]) and want[1:] == got[1:], name
+        if st.hdr.flags & 1:
+            n_strand_tapes += 1
+            ops = st.ops()
+            n_bar = sum(1 for o in ops if o[0] & 0xFF == F.OP_BARRIER)
+            assert n_bar % 4 == 0 and len(ops) - n_bar == plain.hdr.n_ops, name
+            assert (st.hdr.n_constraints, st.hdr.n_mul_ops) == (plain.hdr.n_constraints, plain.hdr.n_mul_ops)
+            assert st.hdr.n_xslots <= 32
+            # the Python interpreter agrees on one vector
+            o_py, u_py, _ = F.eval_tape_one(ops, st.consts(), vecs[0], strand_ops=list(st.hdr.strand_ops))
+            assert [o_py[k] for k in range(st.hdr.n_outputs)] == z.unpack_outputs(got[0])[0] and u_py == []
+        else:
+            assert st.blob() == plain.blob(), name  # fell back: the plain tape, bit for bit
+    assert n_strand_tapes >= 10
+
+
+def test_a_broken_constraint_keeps_its_number_in_a_strand_tape():
+    circuit = z.poseidon_style_gadget(4, 6, 3)
+    plain = z.Lowerer(circuit).lower()
+    st = z.Lowerer(circuit, _strand_options()).lower()
+    assert st.hdr.flags & 1
+    rnd = random.Random(2)
+    vecs = [[rnd.randrange(F.P) for _ in range(4)] for _ in range(5)]
+    inp = z.pack_inputs(vecs, 4)
+    # swap the c operand of constraint 17 for a constant in both tapes
+    def broken(t):
+        ops = [list(o) for o in t.ops()]
+        k = 0
+        for o in ops:
+            if o[0] & 0xFF == F.OP_CHECK:
+                idx = (o[0] >> 8) - 1 if t.hdr.flags & 1 else k
+                k += 1
+                if idx == 17:
+                    o[1] = K(0)
+        blob = b"".join(struct.pack("<4I", *o) for o in ops) + t.blob()[16 * t.hdr.n_ops:]
+        return C.eval_cpu(bytes(t.hdr), blob, inp, len(vecs), t.hdr.n_outputs)
+    a, b = broken(plain), broken(st)
+    assert a[1] == b[1] == len(vecs) and a[2] == b[2] == (0, 17)
+
+
+def test_strand_lowering_refuses_nothing_and_falls_back():
+    # operators beyond + - *: plain tape; exchange slots beyond the cap: plain tape; strands must be 0 or 4
+    c = z.Generator(5).generate()  # reference-shaped: every operator
+    try:
+        t = z.Lowerer(c, _strand_options()).lower()
+        assert t.hdr.flags == 0
+    except z.LowerRejected:
+        pass
+    big = z.Generator(7, _ext_config(900)).generate()
+    assert z.Lowerer(big, _strand_options()).lower().hdr.flags == 0
+    assert z.Lowerer(z.poseidon_style_gadget(4, 5, 1), _strand_options(max_xslots=2)).lower().hdr.flags == 0
+    with pytest.raises(z.ZkirError):
+        z.Lowerer(z.poseidon_style_gadget(4, 5, 1), _strand_options(strands=3)).lower()
+
+
+@pytest.mark.gpu
+def test_lowered_strand_tapes_on_the_gpu():
+    rnd = random.Random(10)
+    ctx = z.Context(0)
+    try:
+        n_strand_tapes = 0
+        for name, circuit, n_in in _circuits():
+            st = z.Lowerer(circuit, _strand_options()).lower()
+            n_strand_tapes += st.hdr.flags & 1
+            n = rnd.choice([1, 63, 64, 65, 200, 777])
+            vecs = [[rnd.randrange(F.P) for _ in range(n_in)] for _ in range(n)]
+            inp = z.pack_inputs(vecs, n_in)
+            tid = ctx.upload(st)
+            out, unsat, first, faults = ctx.eval_batch(tid, inp, n)
+            ctx.release(tid)
+            o_c, u_c, first_c, f_c = C.eval_cpu(bytes(st.hdr), st.blob(), inp, n, st.hdr.n_outputs)
+            assert np.array_equal(out, o_c), name
+            assert (unsat, first, faults) == (u_c, first_c, f_c) == (0, None, 0), name
+        assert n_strand_tapes >= 10
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_strand_and_plain_tapes_do_not_share_a_launch_and_many_strand_tapes_do():
+    ctx = z.Context(0)
+    try:
+        tapes = [z.Lowerer(z.poseidon_style_gadget(4, 3 + k, k + 1), _strand_options()).lower() for k in range(6)]
+        assert all(t.hdr.flags & 1 for t in tapes)
+        n = 130
+        rnd = random.Random(3)
+        tids = [ctx.upload(t) for t in tapes]
+        blocks, want = [], []
+        for t in tapes:
+            vecs = [[rnd.randrange(F.P) for _ in range(4)] for _ in range(n)]
+            inp = z.pack_inputs(vecs, 4)
+            blocks.append(inp.reshape(-1))
+            want.append(C.eval_cpu(bytes(t.hdr), t.blob(), inp, n, t.hdr.n_outputs)[1])
+        unsat, faults = ctx.eval_multi(tids, np.concatenate(blocks), n)
+        assert list(unsat) == want == [0] * len(tapes) and faults == 0
+        plain = ctx.upload(z.Lowerer(z.poseidon_style_gadget(4, 3, 1)).lower())
+        with pytest.raises(z.ZkirError):
+            ctx.eval_multi([tids[0], plain], np.concatenate(blocks[:2]), n)
+    finally:
+        ctx.close()

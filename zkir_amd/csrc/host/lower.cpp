@@ -8,8 +8,10 @@
 #include "lower.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <queue>
 #include <unordered_map>
 
 #include "fr_host.hpp"
@@ -494,28 +496,36 @@ struct Home {
   uint32_t operand = ZKIR_OPERAND_NONE;  // GSLOT / LSLOT operand, or NONE when the value only lives in the accumulator
 };
 
-}  // namespace
+// One op stream (the whole tape, or one strand of a strand tape) gets its accumulator
+// forwarding and its private slots here.  `xhome[v]` is the exchange-slot operand of a value
+// that other strands read (strand tapes only; ZKIR_OPERAND_NONE otherwise); `check_id[i]` is the
+// constraint number of CHECK op i of `all`, written into the op when `carry_ids`.
+struct StreamOut {
+  std::vector<zkir_op> ops;
+  uint32_t n_g = 0, used_l = 0, n_mul = 0;
+};
 
-Tape Lowerer::lower() {
-  if (opts_.n_lslots > ZKIR_MAX_LSLOTS) throw LowerError(ZKIR_LOWER_BAD_AST, "n_lslots above ZKIR_MAX_LSLOTS");
-  Pass1 p1(circuit, opts_);
-  p1.run();
-  const std::vector<SOp>& ops = p1.ops;
-  const size_t n = ops.size();
-  const int32_t nv = p1.n_values;
-
-  auto defines = [](const SOp& o) { return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP; };
+StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>& stream, int32_t nv,
+                       const std::vector<uint32_t>& xhome, const std::vector<uint32_t>& check_id, bool carry_ids,
+                       const LowerOptions& opts, std::vector<uint32_t>* triples) {
+  const size_t n = stream.size();
+  auto op_at = [&](size_t i) -> const SOp& { return all[stream[i]]; };
+  auto defines = [](const SOp& o) {
+    return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP && o.code != ZKIR_OP_BARRIER;
+  };
+  auto is_x = [&](Ref r) { return !xhome.empty() && (xhome[r] >> ZKIR_KIND_SHIFT) == ZKIR_KIND_XSLOT; };
 
   // last op that reads each value, and whether every read can come from the accumulator:
   // the accumulator holds value v from its defining op until the next defining op has run
   std::vector<int64_t> def_at(nv, -1), last_use(nv, -1);
   std::vector<int64_t> next_def(n + 1, (int64_t)n);  // index of the first defining op at or after i
-  for (int64_t i = (int64_t)n - 1; i >= 0; i--) next_def[i] = defines(ops[i]) ? i : next_def[i + 1];
+  for (int64_t i = (int64_t)n - 1; i >= 0; i--) next_def[i] = defines(op_at(i)) ? i : next_def[i + 1];
   auto note_use = [&](Ref r, int64_t at) {
     if (r >= 0) last_use[r] = std::max(last_use[r], at);
   };
   for (size_t i = 0; i < n; i++) {
-    const SOp& o = ops[i];
+    const SOp& o = op_at(i);
+    if (o.code == ZKIR_OP_BARRIER) continue;
     if (o.code == ZKIR_OP_INPUT) {
       def_at[o.dst] = (int64_t)i;
       continue;
@@ -528,29 +538,35 @@ Tape Lowerer::lower() {
 
   std::vector<Home> home(nv);
   std::vector<uint32_t> free_l, free_g;
-  for (uint32_t k = opts_.n_lslots; k-- > 0;) free_l.push_back(k);
-  uint32_t n_g = 0, used_l = 0;
+  for (uint32_t k = opts.n_lslots; k-- > 0;) free_l.push_back(k);
   // values whose slot is released after op i
   std::vector<std::vector<int32_t>> dies_at(n);
-  const int64_t kWindowLifetime = opts_.window_lifetime ? opts_.window_lifetime : 48;
+  const int64_t kWindowLifetime = opts.window_lifetime ? opts.window_lifetime : 48;
 
-  std::vector<zkir_op> out_ops(n);
-  uint32_t n_checks = 0, n_mul = 0;
-  std::vector<uint32_t> triples;
+  StreamOut out;
+  out.ops.resize(n);
 
   auto src_operand = [&](Ref r, size_t at) -> uint32_t {
     if (r == kNoRef) return ZKIR_OPERAND_NONE;
     if (is_const(r)) return ZKIR_OPERAND(ZKIR_KIND_CONST, const_index(r));
-    // in the accumulator iff no defining op lies strictly between its definition and this use
-    if (opts_.use_acc && next_def[def_at[r] + 1] >= (int64_t)at) return ZKIR_OPERAND_ACC;
-    if ((home[r].operand >> ZKIR_KIND_SHIFT) == ZKIR_KIND_NONE) throw LowerError(ZKIR_LOWER_BAD_AST, "internal: value has no home");
+    // in the accumulator iff this stream defined it and no defining op lies strictly between
+    // its definition and this use
+    if (opts.use_acc && def_at[r] >= 0 && next_def[def_at[r] + 1] >= (int64_t)at) return ZKIR_OPERAND_ACC;
+    if (is_x(r)) return xhome[r];
+    if (def_at[r] < 0 || (home[r].operand >> ZKIR_KIND_SHIFT) == ZKIR_KIND_NONE)
+      throw LowerError(ZKIR_LOWER_BAD_AST, "internal: value has no home");
     return home[r].operand;
   };
 
   for (size_t i = 0; i < n; i++) {
-    const SOp& o = ops[i];
+    const SOp& o = op_at(i);
     zkir_op t{};
     t.code = o.code;
+    if (o.code == ZKIR_OP_BARRIER) {
+      t.dst = t.a = t.b = ZKIR_OPERAND_NONE;
+      out.ops[i] = t;
+      continue;
+    }
     if (o.code == ZKIR_OP_INPUT) {
       t.a = ZKIR_OPERAND(ZKIR_KIND_INPUT, (uint32_t)o.a);
       t.b = ZKIR_OPERAND_NONE;
@@ -567,39 +583,44 @@ Tape Lowerer::lower() {
       t.dst = (uint32_t)o.dst;
     } else if (o.code == ZKIR_OP_CHECK) {
       t.dst = src_operand(o.dst, i);
-      triples.push_back(t.a);
-      triples.push_back(t.b);
-      triples.push_back(t.dst);
-      n_checks++;
+      const uint32_t id = check_id[stream[i]];
+      if (carry_ids) t.code |= (id + 1) << 8;
+      if (triples) {
+        (*triples)[3 * (size_t)id] = t.a;
+        (*triples)[3 * (size_t)id + 1] = t.b;
+        (*triples)[3 * (size_t)id + 2] = t.dst;
+      }
     } else {
-      if (o.code == ZKIR_OP_MUL) n_mul++;
+      if (o.code == ZKIR_OP_MUL) out.n_mul++;
       const int32_t v = o.dst;
       // does any read fall outside the accumulator's reach?
-      const bool acc_only = opts_.use_acc && last_use[v] < next_def[i + 1] + 1 && last_use[v] <= next_def[i + 1];
-      if (last_use[v] < 0 || acc_only) {
+      const bool acc_only = opts.use_acc && last_use[v] < next_def[i + 1] + 1 && last_use[v] <= next_def[i + 1];
+      if (is_x(v)) {
+        t.dst = xhome[v];  // other strands read it: it lives in its exchange slot, for this strand too
+      } else if (last_use[v] < 0 || acc_only) {
         t.dst = ZKIR_OPERAND_NONE;
       } else {
         const bool window_ok = !free_l.empty() && (last_use[v] - (int64_t)i) <= kWindowLifetime;
         if (window_ok) {
           const uint32_t s = free_l.back();
           free_l.pop_back();
-          used_l = std::max(used_l, s + 1);
+          out.used_l = std::max(out.used_l, s + 1);
           home[v].operand = ZKIR_OPERAND(ZKIR_KIND_LSLOT, s);
         } else {
           uint32_t s;
-          if (!free_g.empty() && opts_.reuse_slots) {
+          if (!free_g.empty() && opts.reuse_slots) {
             s = free_g.back();
             free_g.pop_back();
           } else {
-            s = n_g++;
+            s = out.n_g++;
           }
           home[v].operand = ZKIR_OPERAND(ZKIR_KIND_GSLOT, s);
         }
         t.dst = home[v].operand;
-        if (opts_.reuse_slots) dies_at[(size_t)last_use[v]].push_back(v);
+        if (opts.reuse_slots) dies_at[(size_t)last_use[v]].push_back(v);
       }
     }
-    out_ops[i] = t;
+    out.ops[i] = t;
     // release the slots of values read for the last time by this op; a slot freed here can
     // be the destination of a LATER op only, never of this one (its store is already placed)
     for (int32_t v : dies_at[i]) {
@@ -608,19 +629,164 @@ Tape Lowerer::lower() {
       if (kind == ZKIR_KIND_GSLOT) free_g.push_back(idx);
     }
   }
+  return out;
+}
 
-  Tape tape;
-  zkir_tape_hdr& h = tape.hdr;
-  h.magic = ZKIR_TAPE_MAGIC;
-  h.version = ZKIR_TAPE_VERSION;
-  h.n_inputs = (uint32_t)p1.n_inputs;
-  h.n_outputs = (uint32_t)p1.n_outputs;
-  h.n_consts = (uint32_t)p1.consts.size();
-  h.n_ops = (uint32_t)n;
-  h.n_gslots = n_g;
-  h.n_lslots = used_l;
-  h.n_constraints = n_checks;
-  h.n_mul_ops = n_mul;
+// ---- strands: which op runs in which of the four op streams, and between which barriers ----
+// The strands advance in epochs (the stretches between barriers): an op may use a value of
+// its own strand at once, a value of another strand only in a later epoch.  The schedule is
+// built epoch by epoch with a clock per strand (a product, a check or an input costs 12
+// units, an output conversion 6, everything else 1): the strand that is least far along takes
+// the next op it may run, in program order; a strand with nothing to run waits.  The epoch
+// ends when every strand waits, or when half of them wait while ops exist that only a barrier
+// can release (they read values two strands made in this epoch, or sit behind a busy strand).
+// Independent chains of a circuit spread over the strands that way, each epoch ends with the
+// strands about equally far along, and a barrier falls where values have to cross.
+struct Placement {
+  std::vector<uint8_t> strand;             // per op
+  std::vector<int32_t> epoch;              // per op
+  std::vector<uint32_t> order[ZKIR_STRANDS];  // ops of each strand in the order they run
+  int32_t n_epochs = 1;
+};
+
+Placement place_strands(const std::vector<SOp>& ops, int32_t nv) {
+  const size_t n = ops.size();
+  Placement pl;
+  pl.strand.assign(n, 0);
+  pl.epoch.assign(n, -1);
+  auto sources = [&](const SOp& o, Ref out[3]) {
+    out[0] = out[1] = out[2] = kNoRef;
+    if (o.code == ZKIR_OP_INPUT || o.code == ZKIR_OP_NOP) return;
+    out[0] = o.a;
+    out[1] = o.b;
+    if (o.code == ZKIR_OP_CHECK) out[2] = o.dst;
+  };
+  auto defines = [](const SOp& o) { return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP; };
+  auto cost = [](uint8_t code) -> uint64_t {
+    switch (code) {
+      case ZKIR_OP_MUL: case ZKIR_OP_CHECK: case ZKIR_OP_INPUT: return 12;
+      case ZKIR_OP_OUTPUT: return 6;
+      default: return 1;
+    }
+  };
+  // who reads each op's value (ops are single assignment and in a valid order: definitions first)
+  std::vector<int32_t> def_op(nv, -1);
+  std::vector<uint32_t> n_wait(n, 0), succ_begin(n + 1, 0);
+  for (size_t i = 0; i < n; i++) {
+    Ref src[3];
+    sources(ops[i], src);
+    for (int k = 0; k < 3; k++) {
+      if (src[k] < 0 || def_op[src[k]] < 0) continue;
+      bool seen = false;  // one edge per distinct producer
+      for (int q = 0; q < k; q++) seen = seen || (src[q] >= 0 && def_op[src[q]] == def_op[src[k]]);
+      if (seen) continue;
+      n_wait[i]++;
+      succ_begin[(size_t)def_op[src[k]] + 1]++;
+    }
+    if (defines(ops[i]) && ops[i].dst >= 0) def_op[ops[i].dst] = (int32_t)i;
+  }
+  for (size_t i = 0; i < n; i++) succ_begin[i + 1] += succ_begin[i];
+  std::vector<uint32_t> succ(succ_begin[n]), fill(succ_begin.begin(), succ_begin.end() - 1);
+  std::fill(def_op.begin(), def_op.end(), -1);
+  for (size_t i = 0; i < n; i++) {
+    Ref src[3];
+    sources(ops[i], src);
+    for (int k = 0; k < 3; k++) {
+      if (src[k] < 0 || def_op[src[k]] < 0) continue;
+      bool seen = false;
+      for (int q = 0; q < k; q++) seen = seen || (src[q] >= 0 && def_op[src[q]] == def_op[src[k]]);
+      if (!seen) succ[fill[def_op[src[k]]]++] = (uint32_t)i;
+    }
+    if (defines(ops[i]) && ops[i].dst >= 0) def_op[ops[i].dst] = (int32_t)i;
+  }
+
+  typedef std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> Heap;  // smallest index first
+  Heap anywhere, bound[ZKIR_STRANDS];
+  std::vector<uint32_t> after_barrier;  // runnable, but its operands come from two strands of this epoch
+  // the strand whose value of the current epoch an unplaced op reads: -1 none, -2 more than one
+  std::vector<int32_t> tie(n, -1), tie_epoch(n, -1);
+  size_t left = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (ops[i].code == ZKIR_OP_NOP) {
+      pl.epoch[i] = 0;
+      continue;
+    }
+    left++;
+    if (n_wait[i] == 0) anywhere.push((uint32_t)i);
+  }
+  uint64_t clock[ZKIR_STRANDS] = {0, 0, 0, 0};
+  bool idle[ZKIR_STRANDS] = {false, false, false, false};
+  int32_t e = 0;
+  const uint64_t kBarrier = 2;
+  auto close_epoch = [&]() {
+    uint64_t t = 0;
+    for (uint64_t c : clock) t = std::max(t, c);
+    for (int s = 0; s < (int)ZKIR_STRANDS; s++) {
+      clock[s] = t + kBarrier;
+      idle[s] = false;
+      while (!bound[s].empty()) {  // what was tied to a strand by a value of this epoch is free to move now
+        anywhere.push(bound[s].top());
+        bound[s].pop();
+      }
+    }
+    for (uint32_t i : after_barrier) anywhere.push(i);
+    after_barrier.clear();
+    e++;
+  };
+  while (left) {
+    int s = -1, n_idle = 0;
+    for (int k = 0; k < (int)ZKIR_STRANDS; k++) {
+      if (idle[k]) {
+        n_idle++;
+        continue;
+      }
+      if (s < 0 || clock[k] < clock[s]) s = k;
+    }
+    bool waiting = !after_barrier.empty();
+    for (int k = 0; k < (int)ZKIR_STRANDS && !waiting; k++) waiting = !bound[k].empty() && idle[k] == false && n_idle > 0;
+    if (s < 0 || (n_idle * 2 >= (int)ZKIR_STRANDS && waiting)) {
+      close_epoch();
+      continue;
+    }
+    uint32_t i;
+    if (!bound[s].empty() && (anywhere.empty() || bound[s].top() < anywhere.top())) {
+      i = bound[s].top();
+      bound[s].pop();
+    } else if (!anywhere.empty()) {
+      i = anywhere.top();
+      anywhere.pop();
+    } else {
+      idle[s] = true;
+      continue;
+    }
+    pl.strand[i] = (uint8_t)s;
+    pl.epoch[i] = e;
+    pl.order[s].push_back(i);
+    clock[s] += cost(ops[i].code);
+    left--;
+    for (uint32_t q = succ_begin[i]; q < succ_begin[i + 1]; q++) {
+      const uint32_t j = succ[q];
+      if (tie_epoch[j] != e) {
+        tie_epoch[j] = e;
+        tie[j] = -1;
+      }
+      tie[j] = tie[j] == -1 || tie[j] == s ? s : -2;
+      if (--n_wait[j] == 0) {
+        if (tie[j] == -2)
+          after_barrier.push_back(j);
+        else
+          bound[tie[j]].push(j);  // its last producer ran in this epoch, so a tie exists
+      }
+    }
+    // a strand that was waiting may have work now only through `anywhere`, which this op cannot
+    // have fed (its readers are tied to strand s): nobody wakes up here
+  }
+  pl.n_epochs = e + 1;
+  return pl;
+}
+
+void write_tape(Tape& tape, const Pass1& p1, const std::vector<zkir_op>& out_ops, const std::vector<uint32_t>& triples) {
+  const size_t n = out_ops.size();
   tape.blob.resize(n * sizeof(zkir_op) + p1.consts.size() * 32 + triples.size() * 4);
   uint8_t* w = tape.blob.data();
   if (n) std::memcpy(w, out_ops.data(), n * sizeof(zkir_op));
@@ -634,6 +800,128 @@ Tape Lowerer::lower() {
   if (!triples.empty()) std::memcpy(w, triples.data(), triples.size() * 4);
   tape.inputs = p1.inputs;
   tape.outputs = p1.outputs;
+}
+
+}  // namespace
+
+Tape Lowerer::lower() {
+  if (opts_.n_lslots > ZKIR_MAX_LSLOTS) throw LowerError(ZKIR_LOWER_BAD_AST, "n_lslots above ZKIR_MAX_LSLOTS");
+  if (opts_.strands != 0 && opts_.strands != ZKIR_STRANDS) throw LowerError(ZKIR_LOWER_BAD_AST, "strands must be 0 or 4");
+  Pass1 p1(circuit, opts_);
+  p1.run();
+  const std::vector<SOp>& ops = p1.ops;
+  const size_t n = ops.size();
+  const int32_t nv = p1.n_values;
+
+  // constraint k is the k-th CHECK in program order, whatever stream it ends up in
+  std::vector<uint32_t> check_id(n, 0);
+  uint32_t n_checks = 0;
+  bool plain_ops_only = true;  // + - * and data movement: what the strand kernel runs
+  for (size_t i = 0; i < n; i++) {
+    if (ops[i].code == ZKIR_OP_CHECK) check_id[i] = n_checks++;
+    const uint8_t c = ops[i].code;
+    if (c == ZKIR_OP_BNOT || c == ZKIR_OP_BNOT256 || (c >= ZKIR_OP_POW && c <= ZKIR_OP_SHL)) plain_ops_only = false;
+  }
+
+  Tape tape;
+  zkir_tape_hdr& h = tape.hdr;
+  h.magic = ZKIR_TAPE_MAGIC;
+  h.version = ZKIR_TAPE_VERSION;
+  h.n_inputs = (uint32_t)p1.n_inputs;
+  h.n_outputs = (uint32_t)p1.n_outputs;
+  h.n_consts = (uint32_t)p1.consts.size();
+  h.n_constraints = n_checks;
+  std::vector<uint32_t> triples((size_t)n_checks * 3, 0);
+
+  if (opts_.strands == ZKIR_STRANDS && plain_ops_only && n_checks < (1u << 24) - 1) {
+    const uint32_t max_x = std::min<uint32_t>(opts_.max_xslots ? opts_.max_xslots : ZKIR_MAX_XSLOTS, ZKIR_MAX_XSLOTS);
+    const Placement pl = place_strands(ops, nv);
+    // values read outside the strand that defines them live in exchange slots.  A slot is free
+    // again for a definition in an epoch after the one of its value's last read: every reader
+    // has then passed the barrier the writer waits at.
+    std::vector<int32_t> def_op(nv, -1), last_read_epoch(nv, -1);
+    std::vector<bool> crosses(nv, false);
+    auto note = [&](Ref r, size_t at) {
+      if (r < 0 || def_op[r] < 0) return;
+      last_read_epoch[r] = std::max(last_read_epoch[r], pl.epoch[at]);
+      if (pl.strand[def_op[r]] != pl.strand[at]) crosses[r] = true;
+    };
+    for (size_t i = 0; i < n; i++) {
+      const SOp& o = ops[i];
+      if (o.code != ZKIR_OP_INPUT) {
+        note(o.a, i);
+        note(o.b, i);
+        if (o.code == ZKIR_OP_CHECK) note(o.dst, i);
+      }
+      const bool defines = o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP;
+      if (defines && o.dst >= 0) def_op[o.dst] = (int32_t)i;
+    }
+    std::vector<uint32_t> xhome(nv, ZKIR_OPERAND_NONE);
+    std::vector<int32_t> slot_free_from;  // per exchange slot: first epoch a new value may be defined in
+    bool fits = true;
+    for (size_t i = 0; i < n && fits; i++) {
+      const SOp& o = ops[i];
+      const bool defines = o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP;
+      if (!defines || o.dst < 0 || !crosses[o.dst]) continue;
+      uint32_t slot = UINT32_MAX;
+      for (uint32_t s = 0; s < slot_free_from.size(); s++)
+        if (slot_free_from[s] <= pl.epoch[i]) {
+          slot = s;
+          break;
+        }
+      if (slot == UINT32_MAX) {
+        if (slot_free_from.size() >= max_x) {
+          fits = false;
+          break;
+        }
+        slot = (uint32_t)slot_free_from.size();
+        slot_free_from.push_back(0);
+      }
+      slot_free_from[slot] = last_read_epoch[o.dst] + 1;
+      xhome[o.dst] = ZKIR_OPERAND(ZKIR_KIND_XSLOT, slot);
+    }
+    if (fits) {
+      // each strand's ops in program order, a barrier wherever its epoch advances, and as many
+      // barriers at its end as it takes for every strand to hold the same number
+      std::vector<SOp> all = ops;
+      const uint32_t barrier_at = (uint32_t)all.size();
+      all.push_back({ZKIR_OP_BARRIER, kNoRef, kNoRef, kNoRef});
+      check_id.push_back(0);
+      std::vector<uint32_t> stream[ZKIR_STRANDS];
+      int32_t at_epoch[ZKIR_STRANDS] = {0, 0, 0, 0};
+      for (int s = 0; s < (int)ZKIR_STRANDS; s++)
+        for (uint32_t i : pl.order[s]) {
+          for (; at_epoch[s] < pl.epoch[i]; at_epoch[s]++) stream[s].push_back(barrier_at);
+          stream[s].push_back(i);
+        }
+      std::vector<zkir_op> out_ops;
+      uint32_t n_mul = 0;
+      for (int s = 0; s < (int)ZKIR_STRANDS; s++) {
+        for (; at_epoch[s] < pl.n_epochs - 1; at_epoch[s]++) stream[s].push_back(barrier_at);
+        StreamOut so = place_stream(all, stream[s], nv, xhome, check_id, true, opts_, &triples);
+        h.strand_ops[s] = (uint32_t)so.ops.size();
+        h.n_gslots = std::max(h.n_gslots, so.n_g);
+        h.n_lslots = std::max(h.n_lslots, so.used_l);
+        n_mul += so.n_mul;
+        out_ops.insert(out_ops.end(), so.ops.begin(), so.ops.end());
+      }
+      h.flags = ZKIR_TAPE_F_STRANDS;
+      h.n_xslots = (uint32_t)slot_free_from.size();
+      h.n_ops = (uint32_t)out_ops.size();
+      h.n_mul_ops = n_mul;
+      write_tape(tape, p1, out_ops, triples);
+      return tape;
+    }
+  }
+
+  std::vector<uint32_t> stream(n);
+  for (size_t i = 0; i < n; i++) stream[i] = (uint32_t)i;
+  StreamOut so = place_stream(ops, stream, nv, {}, check_id, false, opts_, &triples);
+  h.n_ops = (uint32_t)n;
+  h.n_gslots = so.n_g;
+  h.n_lslots = so.used_l;
+  h.n_mul_ops = so.n_mul;
+  write_tape(tape, p1, so.ops, triples);
   return tape;
 }
 
