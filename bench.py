@@ -45,9 +45,12 @@ def workload_tape(z, signal_window=0, linear_terms=1):
     return z.Lowerer(z.Generator(WORKLOAD_SEED, g).generate(), o).lower()
 
 
-def gadget_tape(z, rounds=20834):
-    """configs[4] of BASELINE.json: Poseidon-style chain, width 4, 3*4*rounds constraints."""
+def gadget_tape(z, rounds=20834, strands=0):
+    """configs[4] of BASELINE.json: Poseidon-style chain, width 4, 3*4*rounds constraints.
+    strands=4 lowers it into a strand tape (four wavefronts per 64 vectors): the shape for
+    batches that leave the machine short of wavefronts."""
     o = z.default_lower_options()
+    o.strands = strands
     for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots", "strands", "max_xslots"):
         if os.environ.get("ZKIR_BENCH_" + k.upper()):
             setattr(o, k, int(os.environ["ZKIR_BENCH_" + k.upper()]))
@@ -86,6 +89,9 @@ def main():
                     help="config2 (default, the headline line) or gadget (the deep Poseidon-style chain, "
                          "2^16 vectors, outputs not requested)")
     ap.add_argument("--gadget-rounds", type=int, default=20834)
+    ap.add_argument("--strands", default="auto", choices=["auto", "0", "4"],
+                    help="gadget only: lower into a strand tape (4) or a plain tape (0); auto takes the strand tape "
+                         "when the batch is too small to give every SIMD two wavefronts of a plain tape")
     ap.add_argument("--signal-window", type=int, default=0,
                     help="config2 only: linear terms read the inputs and the last W signals instead of any "
                          "earlier signal (0 = any, the default line)")
@@ -111,11 +117,14 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     gadget = args.workload == "gadget"
-    tape = gadget_tape(z, args.gadget_rounds) if gadget else workload_tape(z, args.signal_window, args.linear_terms)
-    h = tape.hdr
     if gadget and args.log2_vectors == LOG2_VECTORS:
         args.log2_vectors = 16
     n = 1 << args.log2_vectors
+    # 256 CUs x 4 SIMDs x 64 lanes = 2^16 vectors are one wavefront per SIMD of a plain tape; measured: the strand
+    # tape wins up to 2^17 vectors (two wavefronts per SIMD), the plain tape from 2^18 on
+    strands = (4 if n < (1 << 18) else 0) if args.strands == "auto" else int(args.strands)
+    tape = gadget_tape(z, args.gadget_rounds, strands) if gadget else workload_tape(z, args.signal_window, args.linear_terms)
+    h = tape.hdr
     ctx = z.Context(local_rank)
     tid = ctx.upload(tape)
     inp = synthetic_inputs(torch, h.n_inputs, n, device, 1000 + rank)  # every rank its own vectors
@@ -206,6 +215,7 @@ def main():
                 "n_constraints": h.n_constraints, "n_mul_ops": h.n_mul_ops, "n_ops": h.n_ops,
                 "n_inputs": h.n_inputs, "n_outputs": h.n_outputs, "vectors_per_gpu": n,
                 "device_slots": h.n_gslots, "window_slots": h.n_lslots,
+                "strand_tape": bool(h.flags & 1), "exchange_slots": h.n_xslots,
             },
             "fr_mul_per_s": fr_muls * world / (1e3 * elapsed / args.steps * 1e-3),
             "roofline": {

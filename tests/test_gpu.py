@@ -407,13 +407,19 @@ def test_many_distinct_circuits_one_launch_full_width(ctx):
         ctx.release(t)
 
 
-def test_deep_gadget_full_size(ctx):
+@pytest.mark.parametrize("strands", [0, 4])
+def test_deep_gadget_full_size(ctx, strands, interpreter_kernel):
     """The deep chain at its real size: 250 008 constraints over 2^16 vectors, every constraint
-    of every vector holds, and the last outputs of sampled vectors match the checker."""
+    of every vector holds, and the last outputs of sampled vectors match the checker; as a plain
+    tape and as a strand tape (four wavefronts per 64 vectors, the shape for a batch this small)."""
     torch = pytest.importorskip("torch")
-    tape = z.Lowerer(z.poseidon_style_gadget(4, 20834, 7)).lower()
+    if strands and interpreter_kernel == "compiled":
+        pytest.skip("strand tapes run on the generated stream only")
+    o = z.default_lower_options()
+    o.strands = strands
+    tape = z.Lowerer(z.poseidon_style_gadget(4, 20834, 7), o).lower()
     h = tape.hdr
-    assert h.n_constraints == 250008
+    assert h.n_constraints == 250008 and bool(h.flags & 1) == bool(strands)
     n = 1 << 16
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev)

@@ -317,3 +317,93 @@ def test_operand_registers_are_reused_and_invalidated():
     for victim in (True, False):
         got_out, _, _, _ = run_lane(stale, [], inputs, 3, 1, 3, 0, wave=1, lane=40, victim=victim)
         assert got_out == want_out
+
+
+# ---- strand tapes: four wavefronts, one lane of each, sharing LDS and the output buffer -------------
+def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, n_xslots, vec, lane=0):
+    """The same lane of the four wavefronts of a workgroup, each running its strand of `ops` from barrier to
+    barrier in turn.  Returns (outputs, unsat summed over the strands, smallest first-unsat)."""
+    n_vec, n_inputs = len(inputs), len(inputs[0])
+    mem = IM.Memory()
+    words = []
+    for code, dst, a, b in ops:
+        words += [code, dst, a, b]
+    mem.map("ops", OPS_BASE, max(16, 16 * len(ops)), words=words)
+    cw = []
+    for c in consts:
+        cw += F.limbs32(c * R % F.P)
+    mem.map("consts", CST_BASE, max(32, 32 * len(consts)), words=cw)
+    gs_bytes = n_gslots * 8192
+    mem.map("gslots", GS_BASE, max(gs_bytes, 16), writable=True)
+    iw = [0] * (n_inputs * 8 * n_vec)
+    for t, vecvals in enumerate(inputs):
+        for s, x in enumerate(vecvals):
+            for l, w in enumerate(F.limbs32(x)):
+                iw[(s * 8 + l) * n_vec + t] = w
+    mem.map("inputs", IN_BASE, max(16, 4 * len(iw)), words=iw)
+    out_region = mem.map("outputs", OUT_BASE, max(16, 32 * n_outputs * n_vec), writable=True)
+    shared_lds = {}
+    lanes, pcs, begin = [], [], 0
+    for w in range(4):
+        operands = {
+            "%[ops]": OPS_BASE + 16 * begin, "%[n_ops]": strand_ops[w], "%[consts]": CST_BASE, "%[n_consts]": len(consts),
+            "%[gslots]": GS_BASE, "%[gslot_bytes]": gs_bytes, "%[lds_base]": LDS_BASE, "%[evict_below]": 0,
+            "%[in_base]": IN_BASE, "%[out_base]": OUT_BASE, "%[n4]": 4 * n_vec, "%[live]": 0x8000000000000001 | (1 << lane),
+            "%[v_lo]": w * 2048 + lane * 16, "%[v_vec4]": 4 * vec,
+            "%[xbase]": LDS_BASE + n_lslots * 8192, "%[v_x]": lane * 16,
+        }
+        ln = IM.Lane(mem, LDS_BASE + n_lslots * 8192 + n_xslots * 2048, lane, operands, set(range(G.VB, G.V_LAST + 1)),
+                     set(range(G.SB, G.S_LAST + 1)), result_operands=("%[unsat]", "%[first]"))
+        ln.lds = shared_lds
+        lanes.append(ln)
+        pcs.append(0)
+        begin += strand_ops[w]
+    arrived = [0] * 4
+    while any(pc is not None for pc in pcs):
+        for w in range(4):
+            if pcs[w] is not None:
+                pcs[w] = lanes[w].run(PROG, LABELS, pc=pcs[w], stop_at_barrier=True)
+                arrived[w] += pcs[w] is not None
+        assert len({a for a, pc in zip(arrived, pcs) if pc is not None}) <= 1, "wavefronts wait at different barriers"
+    assert len(set(arrived)) == 1, "strands passed different numbers of barriers"
+    outs = []
+    for s in range(n_outputs):
+        limbs = [out_region.words.get(OUT_BASE + 4 * ((s * 8 + l) * n_vec + vec)) for l in range(8)]
+        outs.append(None if None in limbs else F.from_limbs32(limbs))
+    unsat = sum(ln.operand_written["%[unsat]"] for ln in lanes)
+    first = min(ln.operand_written["%[first]"] for ln in lanes)
+    return outs, unsat, first
+
+
+def test_strand_tapes_on_the_model():
+    """Gadget and generated circuits lowered into strand tapes: the stream, run for one lane of each of
+    the four wavefronts with LDS shared between them, gives the big-integer interpreter's outputs;
+    a planted wrong `c` operand is reported under the constraint number its CHECK op carries."""
+    import zkir_amd as z
+    o = z.default_lower_options()
+    o.strands = 4
+    rnd = random.Random(21)
+    g = z.default_generator_config()
+    g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware, g.no_loops, g.safe_array_index = 4, 1, 1, 1, 1, 1
+    g.min_instructions = g.max_instructions = 30
+    circuits = [(z.poseidon_style_gadget(4, 3, 2), 4), (z.poseidon_style_gadget(2, 4, 3), 2),
+                (z.Generator(3, g).generate(), 4), (z.Generator(8, g).generate(), 4)]
+    for circuit, n_in in circuits:
+        t = z.Lowerer(circuit, o).lower()
+        assert t.hdr.flags & 1
+        ops, consts, so = t.ops(), t.consts(), list(t.hdr.strand_ops)
+        inputs = [[rnd.randrange(F.P) for _ in range(n_in)] for _ in range(3)]
+        for vec, lane in ((0, 0), (2, 37)):
+            want, want_unsat, _ = F.eval_tape_one(ops, consts, inputs[vec], strand_ops=so)
+            outs, unsat, first = run_strands(ops, so, consts, inputs, t.hdr.n_outputs, t.hdr.n_lslots, t.hdr.n_gslots,
+                                             t.hdr.n_xslots, vec, lane)
+            assert outs == [want[k] for k in range(t.hdr.n_outputs)] and unsat == 0 and first == 0xFFFFFFFF
+        # plant a fault: constraint 5 compares with constant 0
+        bad = [list(op) for op in ops]
+        for op in bad:
+            if op[0] & 0xFF == F.OP_CHECK and (op[0] >> 8) - 1 == 5:
+                op[1] = O(F.K_CONST, 0)
+        want, want_unsat, _ = F.eval_tape_one(bad, consts, inputs[1], strand_ops=so)
+        outs, unsat, first = run_strands(bad, so, consts, inputs, t.hdr.n_outputs, t.hdr.n_lslots, t.hdr.n_gslots,
+                                         t.hdr.n_xslots, 1, 5)
+        assert want_unsat == [5] and unsat == 1 and first == 5

@@ -11,7 +11,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 ctx = z.Context(0)
 rnd = random.Random(20240611)
 special = [0, 1, 2, F.P - 1, F.P - 2, F.HALF, F.HALF + 1, (1 << 64) - 1, 1 << 253, 253, 254, 255, F.P - 253, F.P - 254]
-done = rejected = bad = full = multi = 0
+done = rejected = bad = full = multi = stranded = 0
 group = []
 t0 = time.time()
 for it in range(N):
@@ -36,6 +36,8 @@ for it in range(N):
     o.fold_constants = rnd.choice([0, 1])
     o.bnot_variant = rnd.choice([0, 1])
     o.max_iterations = 300
+    o.strands = rnd.choice([0, 0, 4])  # strand tapes where the circuit allows (+ - * only, few crossing values)
+    o.max_xslots = rnd.choice([0, 0, 6, 16])
     seed = rnd.randrange(1, 1 << 62)
     try:
         tape = z.Lowerer(z.Generator(seed, g).generate(), o).lower()
@@ -79,21 +81,30 @@ for it in range(N):
             i2 = z.pack_inputs(v2, t.hdr.n_inputs)
             blocks.append(i2.reshape(-1))
             want.append(C.eval_cpu(bytes(t.hdr), t.blob(), i2, nv2, t.hdr.n_outputs, want_outputs=False)[1])
-        tids = [ctx.upload(t) for t in group]
-        got, _ = ctx.eval_multi(tids, np.concatenate(blocks) if blocks else None, nv2)
-        for t in tids:
-            ctx.release(t)
+        # a launch takes strand tapes or plain tapes, not both: one launch per kind
+        got = [None] * len(group)
+        for kind in (0, 1):
+            members = [i for i, t in enumerate(group) if (t.hdr.flags & 1) == kind]
+            if not members:
+                continue
+            tids = [ctx.upload(group[i]) for i in members]
+            part, _ = ctx.eval_multi(tids, np.concatenate([blocks[i] for i in members]), nv2)
+            for t in tids:
+                ctx.release(t)
+            for i, u in zip(members, part):
+                got[i] = u
         if got != want:
             bad += 1
             print("MISMATCH in a multi-tape launch at iteration", it, got, want, flush=True)
         multi += 1
         group = []
     done += 1
+    stranded += tape.hdr.flags & 1
     codes = {c & 0xFF for c, _, _, _ in tape.ops()}
     full += bool(codes - {0, 1, 2, 3, 4, 16, 17, 18, 48})
     if it % 100 == 0:
         print("iter", it, "evaluated", done, "rejected", rejected, "mismatches", bad, "%.0fs" % (time.time() - t0), flush=True)
 os.environ.pop("ZKIR_INTERP", None)
-print("SOAK done: evaluated %d circuits (%d with non-arithmetic operators) and %d multi-tape launches, rejected %d, "
-      "mismatches %d" % (done, full, multi, rejected, bad))
+print("SOAK done: evaluated %d circuits (%d with non-arithmetic operators, %d as strand tapes) and %d multi-tape launches, "
+      "rejected %d, mismatches %d" % (done, full, stranded, multi, rejected, bad))
 sys.exit(1 if bad else 0)
