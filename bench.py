@@ -121,8 +121,8 @@ def main():
         args.log2_vectors = 16
     n = 1 << args.log2_vectors
     # 256 CUs x 4 SIMDs x 64 lanes = 2^16 vectors are one wavefront per SIMD of a plain tape; measured: the strand
-    # tape wins up to 2^17 vectors (two wavefronts per SIMD), the plain tape from 2^18 on
-    strands = (4 if n < (1 << 18) else 0) if args.strands == "auto" else int(args.strands)
+    # tape wins up to 2^18 vectors, the plain tape from 2^19 on (profiles/r01_f_gadget_strands_vs_plain.txt)
+    strands = (4 if n < (1 << 19) else 0) if args.strands == "auto" else int(args.strands)
     tape = gadget_tape(z, args.gadget_rounds, strands) if gadget else workload_tape(z, args.signal_window, args.linear_terms)
     h = tape.hdr
     ctx = z.Context(local_rank)

@@ -896,9 +896,16 @@ Tape Lowerer::lower() {
         }
       std::vector<zkir_op> out_ops;
       uint32_t n_mul = 0;
+      // A strand tape is for launches short of wavefronts, so its workgroups should fit a CU four at a
+      // time: 40 KiB of LDS each.  The exchange slots (2 KiB) come first; the private window rows (8 KiB:
+      // one row holds a slot of all four strands) get what is left, and the other private values go to
+      // device memory, whose latency the additional wavefronts hide.
+      LowerOptions sopts = opts_;
+      const uint32_t x_bytes = (uint32_t)slot_free_from.size() * 2048u, budget = 40u * 1024u;
+      sopts.n_lslots = std::min<uint32_t>(opts_.n_lslots, x_bytes >= budget ? 0u : (budget - x_bytes) / 8192u);
       for (int s = 0; s < (int)ZKIR_STRANDS; s++) {
         for (; at_epoch[s] < pl.n_epochs - 1; at_epoch[s]++) stream[s].push_back(barrier_at);
-        StreamOut so = place_stream(all, stream[s], nv, xhome, check_id, true, opts_, &triples);
+        StreamOut so = place_stream(all, stream[s], nv, xhome, check_id, true, sopts, &triples);
         h.strand_ops[s] = (uint32_t)so.ops.size();
         h.n_gslots = std::max(h.n_gslots, so.n_g);
         h.n_lslots = std::max(h.n_lslots, so.used_l);
