@@ -782,6 +782,83 @@ Placement place_strands(const std::vector<SOp>& ops, int32_t nv) {
     // have fed (its readers are tied to strand s): nobody wakes up here
   }
   pl.n_epochs = e + 1;
+
+  // Second look: an op that ran next to its operand's producer while its only reader sits in another
+  // strand sends its result across.  When several such ops hang on the same value (a value multiplied
+  // by different constants for different sums), it is that one value that should cross, and each op
+  // should run where its reader is, right before it: fewer exchange slots, the same work per epoch.
+  std::vector<uint32_t> n_readers(n, 0), reader(n, 0);
+  for (size_t i = 0; i < n; i++)
+    for (uint32_t q = succ_begin[i]; q < succ_begin[i + 1]; q++) {
+      n_readers[i]++;
+      reader[i] = succ[q];
+    }
+  std::fill(def_op.begin(), def_op.end(), -1);
+  for (size_t i = 0; i < n; i++)
+    if (defines(ops[i]) && ops[i].dst >= 0) def_op[ops[i].dst] = (int32_t)i;
+  auto may_follow = [&](size_t i, uint32_t c) {  // could op i run right before its reader c, in c's strand?
+    if (ops[i].code == ZKIR_OP_INPUT || !defines(ops[i]) || n_readers[i] != 1) return false;
+    if (pl.strand[c] == pl.strand[i]) return false;
+    Ref src[3];
+    sources(ops[i], src);
+    bool has_value = false;
+    for (Ref r : src) {
+      if (r < 0 || def_op[r] < 0) continue;
+      has_value = true;
+      if (pl.epoch[def_op[r]] >= pl.epoch[c]) return false;  // its operand must have crossed a barrier by then
+    }
+    return has_value;
+  };
+  std::vector<uint32_t> n_followers(n, 0);  // per producer: readers that could follow their own reader
+  for (size_t i = 0; i < n; i++) {
+    if (ops[i].code == ZKIR_OP_NOP || !may_follow(i, reader[i])) continue;
+    Ref src[3];
+    sources(ops[i], src);
+    for (Ref r : src)
+      if (r >= 0 && def_op[r] >= 0) n_followers[def_op[r]]++;
+  }
+  std::vector<std::vector<uint32_t>> before(n);  // ops that now run right before op c
+  std::vector<bool> moved(n, false);
+  bool any = false;
+  for (size_t k = n; k-- > 0;) {  // readers first: their own place is final by the time their operands are looked at
+    const size_t i = k;
+    if (ops[i].code == ZKIR_OP_NOP) continue;
+    const uint32_t c = reader[i];
+    if (!may_follow(i, c)) continue;
+    Ref src[3];
+    sources(ops[i], src);
+    bool shared = true;
+    for (Ref r : src)
+      if (r >= 0 && def_op[r] >= 0) shared = shared && n_followers[def_op[r]] >= 2;
+    if (!shared) continue;
+    pl.strand[i] = pl.strand[c];
+    pl.epoch[i] = pl.epoch[c];
+    before[c].push_back((uint32_t)i);
+    moved[i] = true;
+    any = true;
+  }
+  if (any) {
+    std::vector<uint32_t> fresh[ZKIR_STRANDS];
+    // an op and, ahead of it, what follows it (in program order, which is a valid order among them)
+    std::vector<uint32_t> stack;
+    for (int s = 0; s < (int)ZKIR_STRANDS; s++) {
+      for (uint32_t i : pl.order[s]) {
+        if (moved[i]) continue;
+        // depth-first: the ops before i, each preceded by its own followers
+        std::vector<uint32_t> seq;
+        stack.assign(1, i);
+        while (!stack.empty()) {
+          const uint32_t x = stack.back();
+          stack.pop_back();
+          seq.push_back(x);
+          for (uint32_t y : before[x]) stack.push_back(y);
+        }
+        std::sort(seq.begin(), seq.end());  // program order: definitions before uses
+        fresh[s].insert(fresh[s].end(), seq.begin(), seq.end());
+      }
+      pl.order[s].swap(fresh[s]);
+    }
+  }
   return pl;
 }
 
