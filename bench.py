@@ -89,6 +89,9 @@ def main():
                     help="config2 (default, the headline line) or gadget (the deep Poseidon-style chain, "
                          "2^16 vectors, outputs not requested)")
     ap.add_argument("--gadget-rounds", type=int, default=20834)
+    ap.add_argument("--strong", action="store_true",
+                    help="split the 2^log2-vectors batch over the ranks (contiguous ranges) instead of giving every "
+                         "rank a batch of that size: the fixed-size reading of configs 2 and 5")
     ap.add_argument("--strands", default="auto", choices=["auto", "0", "4"],
                     help="gadget only: lower into a strand tape (4) or a plain tape (0); auto takes the strand tape "
                          "when the batch is too small to give every SIMD two wavefronts of a plain tape")
@@ -120,6 +123,10 @@ def main():
     if gadget and args.log2_vectors == LOG2_VECTORS:
         args.log2_vectors = 16
     n = 1 << args.log2_vectors
+    if args.strong:
+        if n % world:
+            raise SystemExit("--strong needs a batch the ranks divide evenly")
+        n //= world  # this rank's contiguous range of the batch
     # 256 CUs x 4 SIMDs x 64 lanes = 2^16 vectors are one wavefront per SIMD of a plain tape; measured: the strand
     # tape wins up to 2^18 vectors, the plain tape from 2^19 on (profiles/r01_f_gadget_strands_vs_plain.txt)
     strands = (4 if n < (1 << 19) else 0) if args.strands == "auto" else int(args.strands)
@@ -190,6 +197,7 @@ def main():
                     traffic = json.load(f)[key]["bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 traffic = None
+        batch_of = "split over the GPUs" if args.strong else "per GPU"
         line = {
             "metric": "R1CS constraint checks/sec over BN254 Fr",
             "value": value,
@@ -199,19 +207,19 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": ("Poseidon-style gadget chain (width 4, %d rounds) x 2^%d vectors per GPU; witness + checks, "
-                             "outputs not requested" % (args.gadget_rounds, args.log2_vectors)) if gadget else
-                            ("one generated circuit (extended generator, seed %d%s) x 2^%d uniform input vectors per GPU; "
+                "workload": ("Poseidon-style gadget chain (width 4, %d rounds) x 2^%d vectors %s; witness + checks, "
+                             "outputs not requested" % (args.gadget_rounds, args.log2_vectors, batch_of)) if gadget else
+                            ("one generated circuit (extended generator, seed %d%s) x 2^%d uniform input vectors %s; "
                              "witness + outputs + checks" % (
                                  WORKLOAD_SEED,
                                  (", %d-term linear parts" % args.linear_terms) +
                                  (", signal window %d" % args.signal_window if args.signal_window else ""),
-                                 args.log2_vectors)),
+                                 args.log2_vectors, batch_of)),
                 "n_constraints": h.n_constraints, "n_mul_ops": h.n_mul_ops, "n_ops": h.n_ops,
                 "n_inputs": h.n_inputs, "n_outputs": h.n_outputs, "vectors_per_gpu": n,
                 "device_slots": h.n_gslots, "window_slots": h.n_lslots,

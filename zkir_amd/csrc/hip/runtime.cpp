@@ -86,6 +86,14 @@ int32_t hip_fail(zkir_ctx* ctx, hipError_t e, const char* what) {
     if (e_ != hipSuccess) return hip_fail(ctx, e_, #expr);  \
   } while (0)
 
+// {unsat count, first unsat pair, faults, spare} = {0, all ones, 0, 0}, written on the stream by the
+// device (no host memory involved, so nothing has to outlive the call)
+hipError_t init_result(uint64_t* result_dev, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(result_dev, 0, 4 * sizeof(uint64_t), s);
+  if (e == hipSuccess) e = hipMemsetAsync(result_dev + 1, 0xff, sizeof(uint64_t), s);
+  return e;
+}
+
 int32_t ensure(zkir_ctx* ctx, void** buf, size_t* have, size_t need) {
   if (*have >= need && *buf) return ZKIR_OK;
   if (*buf) {
@@ -336,8 +344,7 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
   if (it->second.hdr.n_inputs && N && !inputs_soa_dev) return fail(ctx, ZKIR_E_INVALID, "inputs required");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
-  const uint64_t init[4] = {0, ~0ull, 0, 0};
-  HIP_TRY(ctx, hipMemcpyAsync(result_dev, init, sizeof init, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, init_result(result_dev, s));
   return run_tapes(ctx, &tape, 1, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s);
 }
 
@@ -380,8 +387,7 @@ int32_t zkir_eval_multi_dev(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(ctx, hipMemsetAsync(per_tape_unsat_dev, 0, (size_t)n_tapes * sizeof(uint64_t), s));
-  const uint64_t init[4] = {0, ~0ull, 0, 0};
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->result_buf, init, sizeof init, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, init_result((uint64_t*)ctx->result_buf, s));
   return run_tapes(ctx, tapes, n_tapes, inputs_dev, N_per_tape, nullptr, per_tape_unsat_dev,
                    (uint64_t*)ctx->result_buf + 1, s);
 }
@@ -426,9 +432,12 @@ static int32_t time_probe(zkir_ctx* ctx, int which, bool fr, double* out) {
   const int iters = fr ? 64 : 2048;
   uint32_t* buf = nullptr;
   HIP_TRY(ctx, hipMalloc((void**)&buf, (size_t)blocks * 256 * 4));
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    (void)hipFree(buf);
+    return fail(ctx, ZKIR_E_HIP, "rate probe: hipEventCreate failed");
+  }
   auto launch = [&]() {
     return fr ? zkir::launch_fr_mul_rate(buf, blocks, iters, nullptr)
               : zkir::launch_int_mul_rate(which, buf, blocks, iters, nullptr);
