@@ -320,7 +320,7 @@ int32_t zkir_tape_release(zkir_ctx* ctx, zkir_tape_id id);
  *   first_unsat  nullable; [2] = {vector, constraint} of the unsatisfied pair
  *                with the smallest vector index (then smallest constraint),
  *                0xffffffff each when every constraint holds
- * N < 2^32. */
+ * N < 2^32; a strand tape takes N < 2^27 per launch (ZKIR_E_LIMIT beyond). */
 int32_t zkir_eval_batch(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa, uint64_t N,
                         uint32_t* outputs_soa, uint64_t* unsat_count, uint32_t* first_unsat);
 
@@ -334,7 +334,8 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
 /* Many tapes, N_per_tape vectors each: one tape per workgroup.
  *   inputs  concatenation of each tape's [n_inputs][8][N_per_tape] block
  *   per_tape_unsat [n_tapes]  unsatisfied pairs per tape
- * Host pointers. */
+ * Host pointers.  The tapes of one call are all plain tapes or all strand tapes
+ * (ZKIR_E_INVALID otherwise: the two kinds use a workgroup differently). */
 int32_t zkir_eval_multi(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs,
                         uint64_t N_per_tape, uint64_t* per_tape_unsat);
 
