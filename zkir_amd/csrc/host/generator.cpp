@@ -122,12 +122,12 @@ void Generator::ScopeStack::mark_initialized(const VarRef& var_id) {
   if (var_id.idx)
     var.initialized.at(*var_id.idx) = true;
   else
-    var.initialized = std::vector<bool>{true};
+    var.initialized.assign(1, true);
   refresh(lo);
 }
 
 // ---- Generator ----
-void Generator::push_generated(std::vector<Instruction>& out, std::optional<Instruction> instr) {
+void Generator::push_generated(std::vector<Instruction>& out, std::optional<Instruction>&& instr) {
   if (instr) {
     for (Instruction& p : pending_) out.push_back(std::move(p));
     out.push_back(std::move(*instr));
@@ -159,7 +159,7 @@ Circuit Generator::generate() {
 
   scope_stack_.leave_scope();
   if (!scope_stack_.empty()) throw std::logic_error("scope stack not empty");  // generator.rs:161
-  return Circuit(scope_stack_.all_vars, std::move(instructions));
+  return Circuit(std::move(scope_stack_.all_vars), std::move(instructions));  // a Generator is single use
 }
 
 std::optional<Instruction> Generator::generate_instr() {
@@ -411,11 +411,13 @@ std::optional<Expr> Generator::gen_array_index(size_t) {
   array_draws_.clear();
   // a position in 0..=written, not one of the written elements (generator.rs:584): it can
   // name an unwritten element, or one past the end when every element is written
-  for (size_t k = 0; k < n; k++) array_draws_.push_back(rng_.rand(0, scope_stack_.written_count[arrays[k]]));
+  // rand(0, w) with w >= 1 always draws (an array is in the list once an element is written), and
+  // is next() % (w + 1): the stream advances once per array, the division is needed for one
+  for (size_t k = 0; k < n; k++) array_draws_.push_back(rng_.next());
   if (n == 0) return std::nullopt;
   const size_t pick = rng_.rand(0, n - 1);
   chosen_pos = arrays[pick];
-  chosen_idx = array_draws_[pick];
+  chosen_idx = array_draws_[pick] % ((uint64_t)scope_stack_.written_count[chosen_pos] + 1);
   const Variable& v = scope_stack_.flat[chosen_pos];
   if (cfg_.safe_array_index) {  // extension: always a written element
     size_t written = 0;

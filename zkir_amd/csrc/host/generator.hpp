@@ -91,7 +91,7 @@ class Generator {
   // extensions
   std::optional<Instruction> gen_constraint_quadratic();
   Expr gen_linear();
-  void push_generated(std::vector<Instruction>& out, std::optional<Instruction> instr);
+  void push_generated(std::vector<Instruction>& out, std::optional<Instruction>&& instr);
 
   Rng rng_;
   GeneratorConfig cfg_;
