@@ -93,8 +93,7 @@ def main():
                     help="split the 2^log2-vectors batch over the ranks (contiguous ranges) instead of giving every "
                          "rank a batch of that size: the fixed-size reading of configs 2 and 5")
     ap.add_argument("--strands", default="auto", choices=["auto", "0", "4"],
-                    help="gadget only: lower into a strand tape (4) or a plain tape (0); auto takes the strand tape "
-                         "when the batch is too small to give every SIMD two wavefronts of a plain tape")
+                    help="gadget only: lower into a strand tape (4, and auto) or a plain tape (0)")
     ap.add_argument("--signal-window", type=int, default=0,
                     help="config2 only: linear terms read the inputs and the last W signals instead of any "
                          "earlier signal (0 = any, the default line)")
@@ -127,9 +126,9 @@ def main():
         if n % world:
             raise SystemExit("--strong needs a batch the ranks divide evenly")
         n //= world  # this rank's contiguous range of the batch
-    # 256 CUs x 4 SIMDs x 64 lanes = 2^16 vectors are one wavefront per SIMD of a plain tape; measured: the strand
-    # tape wins up to 2^18 vectors, the plain tape from 2^19 on (profiles/r01_f_gadget_strands_vs_plain.txt)
-    strands = (4 if n < (1 << 19) else 0) if args.strands == "auto" else int(args.strands)
+    # measured (profiles/r01_f_gadget_strands_vs_plain.txt): the gadget's strand tape beats its plain tape at every
+    # batch size from 2^13 to 2^21 vectors, by 4x where the plain tape leaves SIMDs without a wavefront
+    strands = 4 if args.strands == "auto" else int(args.strands)
     tape = gadget_tape(z, args.gadget_rounds, strands) if gadget else workload_tape(z, args.signal_window, args.linear_terms)
     h = tape.hdr
     ctx = z.Context(local_rank)
