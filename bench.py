@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-vectors", type=int, default=LOG2_VECTORS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-outputs", action="store_true",
+                    help="config2 only: do not ask for the outputs (witness and checks only): a measurement aid")
     ap.add_argument("--workload", default="config2", choices=["config2", "gadget"],
                     help="config2 (default, the headline line) or gadget (the deep Poseidon-style chain, "
                          "2^16 vectors, outputs not requested)")
@@ -134,7 +136,8 @@ def main():
     ctx = z.Context(local_rank)
     tid = ctx.upload(tape)
     inp = synthetic_inputs(torch, h.n_inputs, n, device, 1000 + rank)  # every rank its own vectors
-    out = None if gadget else torch.empty((h.n_outputs, 8, n), dtype=torch.int32, device=device)
+    want_outputs = not gadget and not args.no_outputs
+    out = torch.empty((h.n_outputs, 8, n), dtype=torch.int32, device=device) if want_outputs else None
     out_ptr = out.data_ptr() if out is not None else None
     res = torch.zeros(4, dtype=torch.int64, device=device)
     totals = torch.zeros(2, dtype=torch.int64, device=device)
@@ -184,11 +187,11 @@ def main():
         mulhi_peak = ctx.int_mul_rate(0)
         fr_peak = ctx.fr_mul_rate()
         achieved = 128.0 * fr_muls / (kernel_ms * 1e-3)
-        alg_bytes = (32 * (h.n_inputs + (0 if gadget else h.n_outputs)) + 4) * n
+        alg_bytes = (32 * (h.n_inputs + (h.n_outputs if want_outputs else 0)) + 4) * n
         # HBM bytes per launch from the counter passes committed under profiles/ (only for the
         # exact workload they were taken on; counters cannot be read from inside this process)
         traffic = None
-        if (not gadget and args.signal_window == 0 and args.log2_vectors == LOG2_VECTORS
+        if (want_outputs and args.signal_window == 0 and args.log2_vectors == LOG2_VECTORS and not args.strong
                 and not any(k.startswith("ZKIR_") for k in os.environ)):
             try:
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
@@ -213,12 +216,12 @@ def main():
             "config": {
                 "workload": ("Poseidon-style gadget chain (width 4, %d rounds) x 2^%d vectors %s; witness + checks, "
                              "outputs not requested" % (args.gadget_rounds, args.log2_vectors, batch_of)) if gadget else
-                            ("one generated circuit (extended generator, seed %d%s) x 2^%d uniform input vectors %s; "
-                             "witness + outputs + checks" % (
-                                 WORKLOAD_SEED,
-                                 (", %d-term linear parts" % args.linear_terms) +
-                                 (", signal window %d" % args.signal_window if args.signal_window else ""),
-                                 args.log2_vectors, batch_of)),
+                            ("one generated circuit (extended generator, seed %d%s) x 2^%d uniform input vectors %s; %s" % (
+                                WORKLOAD_SEED,
+                                (", %d-term linear parts" % args.linear_terms) +
+                                (", signal window %d" % args.signal_window if args.signal_window else ""),
+                                args.log2_vectors, batch_of,
+                                "witness + outputs + checks" if want_outputs else "witness + checks, outputs not requested")),
                 "n_constraints": h.n_constraints, "n_mul_ops": h.n_mul_ops, "n_ops": h.n_ops,
                 "n_inputs": h.n_inputs, "n_outputs": h.n_outputs, "vectors_per_gpu": n,
                 "device_slots": h.n_gslots, "window_slots": h.n_lslots,
