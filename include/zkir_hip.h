@@ -313,6 +313,13 @@ const char* zkir_last_error(const zkir_ctx* ctx);
 int32_t zkir_tape_upload(zkir_ctx* ctx, const zkir_tape_hdr* hdr, const void* blob, size_t bytes, zkir_tape_id* out);
 int32_t zkir_tape_release(zkir_ctx* ctx, zkir_tape_id id);
 
+/* zkir_tape_upload for n tapes at once: one device allocation, one copy and one
+ * conversion kernel for all of them (a campaign uploads hundreds of small tapes per
+ * launch; one by one that costs more than evaluating them).  out[0..n) receives the
+ * ids; on error no tape of the call is uploaded.  Each id is released on its own. */
+int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hdrs, const void* const* blobs,
+                              const size_t* bytes, zkir_tape_id* out);
+
 /* Evaluate one tape for N input vectors; all pointers are HOST memory.
  *   inputs_soa   [n_inputs][8][N]   (may be NULL when n_inputs == 0)
  *   outputs_soa  [n_outputs][8][N]  nullable

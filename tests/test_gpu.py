@@ -274,6 +274,51 @@ def test_many_tapes_one_launch(ctx):
         ctx.release(t)
 
 
+def test_batched_upload_gives_the_same_results(ctx):
+    """zkir_tape_upload_many against one zkir_tape_upload per tape: plain, strand and every-operator tapes in
+    one batch (evaluated one by one), then a multi-tape launch of the batch's plain tapes."""
+    rnd = random.Random(77)
+    so = z.default_lower_options()
+    so.strands = 4
+    tapes = [z.Lowerer(z.Generator(s, ext_config(min_instructions=30 + 9 * s, max_instructions=30 + 9 * s, forced_inputs=3,
+                                                  inputs_readable=1, arithmetic_only=1, quadratic_aware=1, no_loops=1,
+                                                  safe_array_index=1)).generate()).lower() for s in range(1, 9)]
+    tapes.append(z.Lowerer(z.poseidon_style_gadget(4, 5, 2), so).lower())
+    tapes.append(hand_tape([(F.OP_INPUT, G(0), I(0), NONE), (F.OP_LT, G(1), G(0), K(0)), (F.OP_OUTPUT, 0, G(1), NONE)],
+                           [5], 1, 1, 2, 0))
+    ids = ctx.upload_many(tapes)
+    assert len(set(ids)) == len(tapes)
+    n = 70
+    for t, tid in zip(tapes, ids):
+        vecs = random_vectors(rnd, t.hdr.n_inputs, n)
+        inp = z.pack_inputs(vecs, t.hdr.n_inputs)
+        got = ctx.eval_batch(tid, inp, n)
+        single = ctx.upload(t)
+        want = ctx.eval_batch(single, inp, n)
+        ctx.release(single)
+        o_c, u_c, first_c, f_c = C.eval_cpu(bytes(t.hdr), t.blob(), inp, n, t.hdr.n_outputs)
+        assert np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+        assert np.array_equal(got[0], o_c) and got[1:] == (u_c, first_c, f_c)
+    plain = [(t, tid) for t, tid in zip(tapes[:8], ids[:8])]
+    blocks, want = [], []
+    for t, _ in plain:
+        inp = z.pack_inputs(random_vectors(rnd, t.hdr.n_inputs, n), t.hdr.n_inputs)
+        blocks.append(inp.reshape(-1))
+        want.append(C.eval_cpu(bytes(t.hdr), t.blob(), inp, n, t.hdr.n_outputs, want_outputs=False)[1])
+    got, _ = ctx.eval_multi([tid for _, tid in plain], np.concatenate(blocks), n)
+    assert got == want
+    for tid in ids:
+        ctx.release(tid)
+    # a bad tape anywhere in the batch: nothing is uploaded
+    bad_hdr = api.TapeHdr.from_buffer_copy(bytes(tapes[0].hdr))
+    bad_hdr.n_consts += 1  # the blob no longer matches the header
+    class Fake:  # a tape object whose header lies about its blob
+        def __init__(self, t, hdr):
+            self._h, self.hdr = t._h, hdr
+    with pytest.raises(z.ZkirError):
+        ctx.upload_many([tapes[1], Fake(tapes[0], bad_hdr)])
+
+
 def test_campaign_on_one_gpu():
     """The campaign driver with the real evaluator: generated circuits satisfy their own
     constraints for every device-drawn vector, refused circuits are counted by class, and a

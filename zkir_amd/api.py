@@ -87,6 +87,7 @@ def _load():
         "zkir_ctx_destroy": [c_void_p],
         "zkir_tape_upload": [c_void_p, P(TapeHdr), c_void_p, c_size_t, P(c_uint32)],
         "zkir_tape_release": [c_void_p, c_uint32],
+        "zkir_tape_upload_many": [c_void_p, c_uint32, P(TapeHdr), P(c_void_p), P(c_size_t), P(c_uint32)],
         "zkir_eval_batch": [c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, P(c_uint64), P(c_uint32)],
         "zkir_eval_batch_dev": [c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p],
         "zkir_eval_multi": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, P(c_uint64)],
@@ -326,6 +327,23 @@ class Context:
         self._check(lib.zkir_tape_upload(self._h, byref(tape.hdr), blob, len(blob), byref(tid)))
         self._tapes[tid.value] = (tape.hdr.n_inputs, tape.hdr.n_outputs)
         return tid.value
+
+    def upload_many(self, tapes):
+        """zkir_tape_upload_many: one allocation, one copy and one conversion kernel for all of `tapes`."""
+        n = len(tapes)
+        if n == 0:
+            return []
+        hdrs = (TapeHdr * n)(*[t.hdr for t in tapes])
+        blobs, sizes = (c_void_p * n)(), (c_size_t * n)()
+        for k, t in enumerate(tapes):  # pointers into the tapes' own memory: nothing is copied on the host here
+            p, sz = c_void_p(), c_size_t()
+            _host_check(lib.zkir_tape_blob(t._h, byref(p), byref(sz)))
+            blobs[k], sizes[k] = p.value, sz.value
+        ids = (c_uint32 * n)()
+        self._check(lib.zkir_tape_upload_many(self._h, n, hdrs, blobs, sizes, ids))
+        for k, t in enumerate(tapes):
+            self._tapes[ids[k]] = (t.hdr.n_inputs, t.hdr.n_outputs)
+        return list(ids)
 
     def release(self, tid):
         self._check(lib.zkir_tape_release(self._h, tid))

@@ -151,16 +151,14 @@ class GpuEvaluator:
 
     def __call__(self, tapes, n_vectors, circuit_ids):
         torch = self.torch
-        tids = [self.ctx.upload(t) for t in tapes]
+        tids = self.ctx.upload_many(tapes)
         words = sum(t.hdr.n_inputs for t in tapes) * 8 * n_vectors
         inp = torch.randint(0, 1 << 32, (max(words, 1),), dtype=torch.int64, device=self.device,
                             generator=self.gen).to(torch.int32)
-        # keep every element below p: clear the top 4 bits of limb 7 of each element
-        off = 0
-        for t in tapes:
-            blk = inp[off:off + t.hdr.n_inputs * 8 * n_vectors].view(t.hdr.n_inputs, 8, n_vectors)
-            blk[:, 7, :] &= 0x0FFFFFFF
-            off += t.hdr.n_inputs * 8 * n_vectors
+        # keep every element below p: clear the top 4 bits of limb 7 of each element (the tapes' blocks
+        # [n_inputs][8][n_vectors] lie one after the other, so the whole buffer is [elements][8][n_vectors])
+        if words:
+            inp[:words].view(-1, 8, n_vectors)[:, 7, :] &= 0x0FFFFFFF
         unsat = torch.zeros(len(tapes), dtype=torch.int64, device=self.device)
         stream = torch.cuda.current_stream().cuda_stream
         self.ctx.eval_multi_dev(tids, inp.data_ptr(), n_vectors, unsat.data_ptr(), stream)

@@ -69,6 +69,7 @@ struct zkir_ctx {
   std::vector<TapeSlab> slabs;
   hipEvent_t upload_done = nullptr;  // recorded after the latest upload's device work
   bool upload_pending = false;       // an evaluation on another stream must wait for upload_done
+  bool launched_since_sync = false;  // a launch may still be reading tapes: release must wait for the device
 };
 
 namespace {
@@ -243,6 +244,7 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
                                      L.max_gslots, L.max_lslots, unsat_dev, stats_dev, (uint32_t*)ctx->work_counter,
                                      grid, strands, L.max_xslots, stream);
   if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
+  ctx->launched_since_sync = true;
   return ZKIR_OK;
 }
 
@@ -325,12 +327,80 @@ int32_t zkir_tape_upload(zkir_ctx* ctx, const zkir_tape_hdr* hdr, const void* bl
   return ZKIR_OK;
 }
 
+int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hdrs, const void* const* blobs,
+                              const size_t* bytes, zkir_tape_id* out) {
+  if (!ctx || (n && (!hdrs || !blobs || !bytes || !out))) return ZKIR_E_INVALID;
+  if (n == 0) return ZKIR_OK;
+  std::string why;
+  // device layout of the batch: every tape's ops, then (256-byte aligned) every tape's constants,
+  // so that one kernel converts all constants
+  std::vector<DevTape> tapes(n);
+  size_t ops_total = 0, consts_total = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    if (!zkir::check_tape(hdrs[k], blobs[k], bytes[k], &why))
+      return fail(ctx, ZKIR_E_INVALID, "bad tape " + std::to_string(k) + ": " + why);
+    DevTape& t = tapes[k];
+    t.hdr = hdrs[k];
+    for (uint32_t i = 0; i < hdrs[k].n_ops; i++) {
+      const uint32_t c = ((const zkir_op*)blobs[k])[i].code & 0xffu;
+      if (c == ZKIR_OP_BNOT || c == ZKIR_OP_BNOT256 || (c >= ZKIR_OP_POW && c <= ZKIR_OP_SHL)) t.full = true;
+    }
+    if (t.full && (hdrs[k].flags & ZKIR_TAPE_F_STRANDS))
+      return fail(ctx, ZKIR_E_INVALID, "bad tape: strand tapes are made of + - * and data movement only");
+    ops_total += (size_t)hdrs[k].n_ops * sizeof(zkir_op);
+    consts_total += (size_t)hdrs[k].n_consts * 32;
+  }
+  if (consts_total / 32 >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "too many constants in one upload");
+  const size_t consts_off = (ops_total + 255) & ~(size_t)255;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::vector<char> staging;
+  try {
+    staging.resize(consts_off + consts_total);
+  } catch (const std::bad_alloc&) {
+    return fail(ctx, ZKIR_E_NOMEM, "host staging buffer");
+  }
+  void* base = nullptr;
+  int slab = -1;
+  int32_t rc = arena_alloc(ctx, consts_off + consts_total, &base, &slab);
+  if (rc) return rc;
+  size_t o = 0, c = consts_off;
+  for (uint32_t k = 0; k < n; k++) {
+    const size_t ob = (size_t)hdrs[k].n_ops * sizeof(zkir_op), cb = (size_t)hdrs[k].n_consts * 32;
+    if (ob) std::memcpy(staging.data() + o, blobs[k], ob);
+    if (cb) std::memcpy(staging.data() + c, (const char*)blobs[k] + ob, cb);
+    tapes[k].ops = (char*)base + o;
+    tapes[k].consts = (char*)base + c;
+    tapes[k].slab = slab;
+    o += ob;
+    c += cb;
+  }
+  hipError_t e = hipSuccess;
+  if (!staging.empty()) e = hipMemcpy(base, staging.data(), staging.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = zkir::launch_consts_to_mont((uint32_t*)((char*)base + consts_off), (uint32_t)(consts_total / 32), nullptr);
+  if (e == hipSuccess) e = hipEventRecord(ctx->upload_done, nullptr);
+  if (e != hipSuccess) {
+    ctx->slabs[slab].live--;
+    return hip_fail(ctx, e, "tape upload");
+  }
+  ctx->slabs[slab].live += (int)n - 1;  // arena_alloc counted one; every tape is released on its own
+  ctx->upload_pending = true;
+  for (uint32_t k = 0; k < n; k++) {
+    out[k] = ctx->next_id++;
+    ctx->tapes[out[k]] = tapes[k];
+  }
+  return ZKIR_OK;
+}
+
 int32_t zkir_tape_release(zkir_ctx* ctx, zkir_tape_id id) {
   if (!ctx) return ZKIR_E_INVALID;
   auto it = ctx->tapes.find(id);
   if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipDeviceSynchronize());  // no launch may still be reading the tape
+  if (ctx->launched_since_sync) {  // no launch may still be reading the tape
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    ctx->launched_since_sync = false;
+  }
   ctx->slabs[it->second.slab].live--;
   ctx->tapes.erase(it);
   return ZKIR_OK;
