@@ -21,12 +21,23 @@ pub struct TapeHdr {
     pub flags: u32, pub strand_ops: [u32; 4], pub n_xslots: u32,
 }
 
+/// zkir_lower_options of the header; `LowerOptions::default()` is NOT the library's default:
+/// fill it with zkir_lower_options_default, then set `strands = 4` to ask for a strand tape
+/// (four wavefronts per 64 vectors; circuits it does not fit come back as plain tapes).
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct LowerOptions {
+    pub fold_constants: u32, pub n_lslots: u32, pub reuse_slots: u32, pub max_ops: u32, pub bnot_variant: u32,
+    pub use_acc: u32, pub max_iterations: u32, pub window_lifetime: u32, pub strands: u32, pub max_xslots: u32,
+}
+
 #[link(name = "zkir_hip")]
 extern "C" {
     fn zkir_host_last_error() -> *const c_char;
     fn zkir_circuit_parse(text: *const c_char, out: *mut *mut c_void) -> i32;
     fn zkir_circuit_free(c: *mut c_void);
-    fn zkir_lower(c: *const c_void, opts: *const c_void, out: *mut *mut c_void, class: *mut i32) -> i32;
+    fn zkir_lower_options_default(o: *mut LowerOptions) -> i32;
+    fn zkir_lower(c: *const c_void, opts: *const LowerOptions, out: *mut *mut c_void, class: *mut i32) -> i32;
     fn zkir_tape_header(t: *const c_void, hdr: *mut TapeHdr) -> i32;
     fn zkir_tape_blob(t: *const c_void, blob: *mut *const c_void, bytes: *mut usize) -> i32;
     fn zkir_tape_free(t: *mut c_void);
@@ -35,6 +46,11 @@ extern "C" {
     fn zkir_last_error(ctx: *const c_void) -> *const c_char;
     fn zkir_tape_upload(ctx: *mut c_void, hdr: *const TapeHdr, blob: *const c_void, bytes: usize, id: *mut u32) -> i32;
     fn zkir_tape_release(ctx: *mut c_void, id: u32) -> i32;
+    // a launch's worth of tapes in one copy (campaigns); ids come back in `out[0..n)`
+    fn zkir_tape_upload_many(ctx: *mut c_void, n: u32, hdrs: *const TapeHdr, blobs: *const *const c_void,
+                             bytes: *const usize, out: *mut u32) -> i32;
+    fn zkir_eval_multi(ctx: *mut c_void, tapes: *const u32, n_tapes: u32, inputs: *const u32, n_per_tape: u64,
+                       per_tape_unsat: *mut u64) -> i32;
     fn zkir_eval_batch(ctx: *mut c_void, tape: u32, inputs_soa: *const u32, n: u64, outputs_soa: *mut u32,
                        unsat_count: *mut u64, first_unsat: *mut u32) -> i32;
 }
