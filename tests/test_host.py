@@ -386,3 +386,16 @@ def test_cli_reproduces_reference_main(tmp_path):
     out = tmp_path / "circuit.circom"
     cli.main(["--seed", "3", "--out", str(out)])
     assert out.read_text() == cli.render(3)[1]
+
+
+def test_build_entry_does_not_import_the_package():
+    """build() must work in a checkout that has no libzkir_hip.so yet: it may not import zkir_amd
+    (whose import loads the library) before it has built it."""
+    import subprocess
+    import sys
+    code = ("import sys, __graft_entry__ as g; m = g._build_module(); "
+            "assert 'zkir_amd' not in sys.modules and 'zkir_amd.api' not in sys.modules; "
+            "assert callable(m.build); print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr

@@ -54,7 +54,7 @@ class LowerOptions(ctypes.Structure):
 
 def _load():
     if not os.path.exists(LIB_PATH):
-        raise ImportError("%s is missing: build it with `python -m zkir_amd.build` (needs hipcc)" % LIB_PATH)
+        raise ImportError("%s is missing: build it with `python zkir_amd/build.py` (needs hipcc)" % LIB_PATH)
     # One HIP runtime per process.  PyTorch wheels carry their own libamdhip64 / libhsa-runtime64;
     # if the system copies were loaded first and torch's second, the second runtime would find no
     # device.  Importing torch first makes libzkir_hip.so bind to the runtime torch already loaded
