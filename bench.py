@@ -115,10 +115,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU with torch.distributed.run" % (args.gpus, world))
+    # ZKIR_BENCH_REHEARSE=1: every rank on GPU 0 and gloo instead of RCCL, to walk the N > 1 control flow on a
+    # one-GPU box (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
+    rehearse = os.environ.get("ZKIR_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+
+    def all_reduce(t, op=dist.ReduceOp.SUM):
+        if rehearse:  # gloo: reduce on the host
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
 
     gadget = args.workload == "gadget"
     if gadget and args.log2_vectors == LOG2_VECTORS:
@@ -168,12 +184,12 @@ def main():
         totals[0] += res[0]
         totals[1] += h.n_constraints * n
     if world > 1:
-        dist.all_reduce(totals)  # the path's only exchange: mismatch count and checks done
+        all_reduce(totals)  # the path's only exchange: mismatch count and checks done
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     unsat_total, checks_total = (int(v) for v in totals.cpu())
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
