@@ -214,7 +214,8 @@ def main(argv=None):
     ap.add_argument("--circuits", type=int, default=1024)
     ap.add_argument("--vectors", type=int, default=1024, help="input vectors per circuit")
     ap.add_argument("--seed", type=int, default=7)
-    ap.add_argument("--group", type=int, default=512, help="circuits per launch")
+    ap.add_argument("--group", type=int, default=2048,
+                    help="circuits per launch (a launch should hold several times the 1 280 workgroups the GPU runs at once)")
     ap.add_argument("--workers", type=int, default=8, help="host threads that generate and lower, per rank")
     args = ap.parse_args(argv)
 
