@@ -717,6 +717,7 @@ Placement place_strands(const std::vector<SOp>& ops, int32_t nv) {
   uint64_t clock[ZKIR_STRANDS] = {0, 0, 0, 0};
   bool idle[ZKIR_STRANDS] = {false, false, false, false};
   int32_t e = 0;
+  size_t placed_in_epoch = 0;
   const uint64_t kBarrier = 2;
   auto close_epoch = [&]() {
     uint64_t t = 0;
@@ -745,7 +746,12 @@ Placement place_strands(const std::vector<SOp>& ops, int32_t nv) {
     bool waiting = !after_barrier.empty();
     for (int k = 0; k < (int)ZKIR_STRANDS && !waiting; k++) waiting = !bound[k].empty() && idle[k] == false && n_idle > 0;
     if (s < 0 || (n_idle * 2 >= (int)ZKIR_STRANDS && waiting)) {
+      // two barriers in a row with nothing placed between them: no op can ever run (cannot happen
+      // for single-assignment ops in definition order; better an error than a loop)
+      if (placed_in_epoch == 0 && e > 0 && anywhere.empty() && after_barrier.empty() && s < 0)
+        throw LowerError(ZKIR_LOWER_BAD_AST, "internal: strand scheduling made no progress");
       close_epoch();
+      placed_in_epoch = 0;
       continue;
     }
     uint32_t i;
@@ -764,6 +770,7 @@ Placement place_strands(const std::vector<SOp>& ops, int32_t nv) {
     pl.order[s].push_back(i);
     clock[s] += cost(ops[i].code);
     left--;
+    placed_in_epoch++;
     for (uint32_t q = succ_begin[i]; q < succ_begin[i + 1]; q++) {
       const uint32_t j = succ[q];
       if (tie_epoch[j] != e) {
