@@ -274,6 +274,33 @@ def test_many_tapes_one_launch(ctx):
         ctx.release(t)
 
 
+def test_pipelined_result_copy(ctx, monkeypatch):
+    """Results of 128 MiB and more leave the device in pieces through pinned memory while host threads move
+    the previous piece into the caller's buffer (zkir_eval_batch); ZKIR_COPY_PIPELINE=1 forces that path on
+    small results.  Same bytes either way: a result of one partial piece, and one of several pieces."""
+    rnd = random.Random(123)
+    g = ext_config(min_instructions=160, max_instructions=160, forced_inputs=5, inputs_readable=1, arithmetic_only=1,
+                   quadratic_aware=1, no_loops=1, safe_array_index=1)
+    tape = z.Lowerer(z.Generator(9, g).generate()).lower()
+    monkeypatch.setenv("ZKIR_COPY_PIPELINE", "1")
+    for n in (1, 257, 1000):
+        check_against_c_oracle(ctx, tape, random_vectors(rnd, tape.hdr.n_inputs, n))
+    monkeypatch.delenv("ZKIR_COPY_PIPELINE")
+    # several pieces of 64 MiB, the last one partial
+    n = (150 << 20) // (32 * tape.hdr.n_outputs) + 77
+    assert 32 * tape.hdr.n_outputs * n > (128 << 20)
+    base = np.random.default_rng(5).integers(0, 1 << 32, size=(tape.hdr.n_inputs, 8, n), dtype=np.uint64).astype(np.uint32)
+    base[:, 7, :] &= 0x0FFFFFFF
+    tid = ctx.upload(tape)
+    out, unsat, first, faults = ctx.eval_batch(tid, base, n)
+    monkeypatch.setenv("ZKIR_COPY_PIPELINE", "0")
+    out_plain, unsat_plain, _, _ = ctx.eval_batch(tid, base, n)
+    ctx.release(tid)
+    assert np.array_equal(out, out_plain) and (unsat, first, faults) == (0, None, 0) and unsat_plain == 0
+    o_c, u_c, _, _ = C.eval_cpu(bytes(tape.hdr), tape.blob(), base, n, tape.hdr.n_outputs, threads=8)
+    assert u_c == 0 and np.array_equal(out, o_c)
+
+
 def test_batched_upload_gives_the_same_results(ctx):
     """zkir_tape_upload_many against one zkir_tape_upload per tape: plain, strand and every-operator tapes in
     one batch (evaluated one by one), then a multi-tape launch of the batch's plain tapes."""

@@ -10,6 +10,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/zkir_hip.h"
@@ -66,6 +67,10 @@ struct zkir_ctx {
   void* io_unsat = nullptr;
   size_t io_unsat_bytes = 0;
   uint64_t last_faults = 0;
+  // the host-pointer entry point's copy pipeline for large results
+  hipStream_t pipe_stream = nullptr;
+  hipEvent_t pipe_done[2] = {nullptr, nullptr};
+  void* pipe_stage[2] = {nullptr, nullptr};  // pinned host memory: a piece of the result on its way to the caller
   std::vector<TapeSlab> slabs;
   hipEvent_t upload_done = nullptr;  // recorded after the latest upload's device work
   bool upload_pending = false;       // an evaluation on another stream must wait for upload_done
@@ -286,6 +291,11 @@ int32_t zkir_ctx_destroy(zkir_ctx* ctx) {
   void* bufs[] = {ctx->gslot_pool, ctx->desc_buf, ctx->result_buf, ctx->work_counter, ctx->io_in, ctx->io_out, ctx->io_unsat};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  for (void* b : ctx->pipe_stage)
+    if (b) (void)hipHostFree(b);
+  for (hipEvent_t ev : ctx->pipe_done)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->pipe_stream) (void)hipStreamDestroy(ctx->pipe_stream);
   delete ctx;
   return ZKIR_OK;
 }
@@ -418,6 +428,55 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
   return run_tapes(ctx, &tape, 1, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s);
 }
 
+namespace {
+
+// `bytes` from pinned memory into the caller's (pageable) memory on a few host threads: one thread copies
+// at about 20 GB/s, the link delivers close to 60
+void parallel_copy(char* dst, const char* src, size_t bytes) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>((size_t)6, (size_t)(hw ? hw : 1)));
+  if (n_threads == 1 || bytes < ((size_t)8 << 20)) {
+    std::memcpy(dst, src, bytes);
+    return;
+  }
+  const size_t per = ((bytes + n_threads - 1) / n_threads + 4095) & ~(size_t)4095;
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < n_threads; t++)
+    if (t * per < bytes) pool.emplace_back([=] { std::memcpy(dst + t * per, src + t * per, std::min(per, bytes - t * per)); });
+  std::memcpy(dst, src, std::min(per, bytes));
+  for (std::thread& th : pool) th.join();
+}
+
+// Device to pageable host memory for large results: pieces go to pinned memory by DMA (two buffers),
+// and while piece k is on the link, host threads move piece k-1 from pinned memory into the caller's
+// buffer.  A plain hipMemcpy into pageable memory does the same with one thread.
+int32_t copy_out_pipelined(zkir_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+  const size_t piece = (size_t)64 << 20;
+  if (!ctx->pipe_stream) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking));
+    for (hipEvent_t& ev : ctx->pipe_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  for (void*& b : ctx->pipe_stage)
+    if (!b && hipHostMalloc(&b, piece, hipHostMallocDefault) != hipSuccess) return fail(ctx, ZKIR_E_NOMEM, "pinned staging buffer");
+  hipStream_t s = ctx->pipe_stream;
+  const size_t n = (bytes + piece - 1) / piece;
+  auto size_of = [&](size_t k) { return std::min(piece, bytes - k * piece); };
+  for (size_t k = 0; k < n; k++) {
+    // buffer k&1 was emptied into the caller's memory before piece k-1 was waited for (below)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pipe_stage[k & 1], (const char*)src_dev + k * piece, size_of(k), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->pipe_done[k & 1], s));
+    if (k > 0) {
+      HIP_TRY(ctx, hipEventSynchronize(ctx->pipe_done[(k - 1) & 1]));
+      parallel_copy((char*)dst_host + (k - 1) * piece, (const char*)ctx->pipe_stage[(k - 1) & 1], size_of(k - 1));
+    }
+  }
+  HIP_TRY(ctx, hipEventSynchronize(ctx->pipe_done[(n - 1) & 1]));
+  parallel_copy((char*)dst_host + (n - 1) * piece, (const char*)ctx->pipe_stage[(n - 1) & 1], size_of(n - 1));
+  return ZKIR_OK;
+}
+
+}  // namespace
+
 int32_t zkir_eval_batch(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa, uint64_t N, uint32_t* outputs_soa,
                         uint64_t* unsat_count, uint32_t* first_unsat) {
   if (!ctx || !unsat_count) return ZKIR_E_INVALID;
@@ -440,7 +499,18 @@ int32_t zkir_eval_batch(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs
   if (rc) return rc;
   uint64_t res[4];
   HIP_TRY(ctx, hipMemcpy(res, ctx->result_buf, sizeof res, hipMemcpyDeviceToHost));
-  if (outputs_soa && out_bytes) HIP_TRY(ctx, hipMemcpy(outputs_soa, ctx->io_out, out_bytes, hipMemcpyDeviceToHost));
+  if (outputs_soa && out_bytes) {
+    // ZKIR_COPY_PIPELINE=0 / 1 forces the plain copy / the pipelined one (test aid); by default the
+    // pipeline takes results of 128 MiB and more
+    const char* force = std::getenv("ZKIR_COPY_PIPELINE");
+    const bool piped = force ? force[0] == '1' : out_bytes >= ((size_t)128 << 20);
+    if (piped) {
+      rc = copy_out_pipelined(ctx, outputs_soa, ctx->io_out, out_bytes);  // res above was copied after the launch: it has finished
+      if (rc) return rc;
+    } else {
+      HIP_TRY(ctx, hipMemcpy(outputs_soa, ctx->io_out, out_bytes, hipMemcpyDeviceToHost));
+    }
+  }
   *unsat_count = res[0];
   ctx->last_faults = res[2];
   if (first_unsat) {
