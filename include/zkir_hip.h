@@ -341,8 +341,8 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
 /* Many tapes, N_per_tape vectors each: one tape per workgroup.
  *   inputs  concatenation of each tape's [n_inputs][8][N_per_tape] block
  *   per_tape_unsat [n_tapes]  unsatisfied pairs per tape
- * Host pointers.  The tapes of one call are all plain tapes or all strand tapes
- * (ZKIR_E_INVALID otherwise: the two kinds use a workgroup differently). */
+ * Host pointers.  Plain and strand tapes may share a call (they run as two launches,
+ * since the two kinds use a workgroup differently). */
 int32_t zkir_eval_multi(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs,
                         uint64_t N_per_tape, uint64_t* per_tape_unsat);
 

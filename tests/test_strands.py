@@ -244,24 +244,42 @@ def test_lowered_strand_tapes_on_the_gpu():
 
 
 @pytest.mark.gpu
-def test_strand_and_plain_tapes_do_not_share_a_launch_and_many_strand_tapes_do():
+def test_strand_and_plain_tapes_in_one_call():
+    """zkir_eval_multi over strand tapes, over plain tapes and over both kinds mixed (two launches behind
+    one call): per-tape counts in the caller's order, a planted fault found in either kind."""
     ctx = z.Context(0)
     try:
-        tapes = [z.Lowerer(z.poseidon_style_gadget(4, 3 + k, k + 1), _strand_options()).lower() for k in range(6)]
-        assert all(t.hdr.flags & 1 for t in tapes)
+        circuits = [z.poseidon_style_gadget(4, 3 + k, k + 1) for k in range(6)]
+        strand = [z.Lowerer(c, _strand_options()).lower() for c in circuits]
+        plain = [z.Lowerer(c).lower() for c in circuits]
+        assert all(t.hdr.flags & 1 for t in strand) and not any(t.hdr.flags & 1 for t in plain)
+
+        def broken(t):  # constraint 2 compared with a constant: fails for every vector
+            ops = [list(o) for o in t.ops()]
+            k = 0
+            for o in ops:
+                if o[0] & 0xFF == F.OP_CHECK:
+                    idx = (o[0] >> 8) - 1 if t.hdr.flags & 1 else k
+                    k += 1
+                    if idx == 2:
+                        o[1] = K(0)
+            blob = b"".join(struct.pack("<4I", *o) for o in ops) + t.blob()[16 * t.hdr.n_ops:]
+            return z.Tape.from_parts(t.hdr, blob)
+
         n = 130
         rnd = random.Random(3)
-        tids = [ctx.upload(t) for t in tapes]
-        blocks, want = [], []
-        for t in tapes:
-            vecs = [[rnd.randrange(F.P) for _ in range(4)] for _ in range(n)]
-            inp = z.pack_inputs(vecs, 4)
-            blocks.append(inp.reshape(-1))
-            want.append(C.eval_cpu(bytes(t.hdr), t.blob(), inp, n, t.hdr.n_outputs)[1])
-        unsat, faults = ctx.eval_multi(tids, np.concatenate(blocks), n)
-        assert list(unsat) == want == [0] * len(tapes) and faults == 0
-        plain = ctx.upload(z.Lowerer(z.poseidon_style_gadget(4, 3, 1)).lower())
-        with pytest.raises(z.ZkirError):
-            ctx.eval_multi([tids[0], plain], np.concatenate(blocks[:2]), n)
+        for tapes in (strand, plain, [strand[0], plain[1], broken(strand[2]), plain[3], strand[4], broken(plain[5])]):
+            tids = ctx.upload_many(tapes)
+            blocks, want = [], []
+            for t in tapes:
+                vecs = [[rnd.randrange(F.P) for _ in range(4)] for _ in range(n)]
+                inp = z.pack_inputs(vecs, 4)
+                blocks.append(inp.reshape(-1))
+                want.append(C.eval_cpu(bytes(t.hdr), t.blob(), inp, n, t.hdr.n_outputs, want_outputs=False)[1])
+            unsat, faults = ctx.eval_multi(tids, np.concatenate(blocks), n)
+            assert list(unsat) == want and faults == 0
+            assert sum(1 for u in unsat if u) == (2 if len({t.hdr.flags for t in tapes}) == 2 else 0)
+            for tid in tids:
+                ctx.release(tid)
     finally:
         ctx.close()

@@ -20,7 +20,8 @@ struct TapeDesc {
   uint32_t n_constraints;
   uint32_t n_consts;
   uint32_t n_xslots;       // strand tapes: exchange slots
-  uint32_t reserved[2];
+  uint32_t unsat_index;    // which entry of the launch's per-tape unsat array this tape counts into
+  uint32_t reserved;
   uint32_t strand_begin[ZKIR_STRANDS];  // strand tapes: first op of each strand
   uint32_t strand_ops[ZKIR_STRANDS];    // strand tapes: ops of each strand
 };

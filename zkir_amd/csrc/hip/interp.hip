@@ -331,7 +331,7 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
     // one atomic per wave for the counters, one per failing lane for the minimum
     const uint64_t wave_faults = __popcll(__ballot(live && fault != 0));
     if ((threadIdx.x & 63) == 0) {
-      if (wave_unsat) atomicAdd((unsigned long long*)&unsat_per_tape[tape_i], (unsigned long long)wave_unsat);
+      if (wave_unsat) atomicAdd((unsigned long long*)&unsat_per_tape[td.unsat_index], (unsigned long long)wave_unsat);
       if (wave_faults) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)wave_faults);
     }
     if (first_bad != 0xffffffffu)
@@ -407,7 +407,7 @@ zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, ui
                  : ZKIR_INTERP_CORE_CLOBBERS);
 
     if (lane == 0 && wave_unsat)
-      atomicAdd((unsigned long long*)&unsat_per_tape[tape_i], (unsigned long long)wave_unsat);
+      atomicAdd((unsigned long long*)&unsat_per_tape[td.unsat_index], (unsigned long long)wave_unsat);
     if (live && first_bad != 0xffffffffu)
       atomicMin((unsigned long long*)&stats[0], (unsigned long long)((vec << 32) | first_bad));
   }

@@ -164,21 +164,25 @@ int pick_variant(bool full, uint64_t N) {
   return N * 32 < (1ull << 32) ? 2 : 0;
 }
 
+// The tapes of one call, split by kind: plain tapes run 256 vectors per workgroup, strand tapes 64 (their
+// four wavefronts are the four strands), so a call that holds both becomes two launches on the same
+// stream.  Input / output offsets and the unsat index of a tape are those of its place in the call.
 struct Launch {
   std::vector<TapeDesc> descs;
   bool full = false;
-  uint32_t n_strand_tapes = 0;  // a launch is all strand tapes or none
   uint32_t max_gslots = 0, max_lslots = 0, max_xslots = 0;
 };
 
-int32_t build_launch(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, uint64_t N, Launch* L) {
+int32_t build_launches(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, uint64_t N, Launch L[2]) {
   uint64_t in_off = 0, out_off = 0;
-  L->descs.resize(n);
   for (uint32_t i = 0; i < n; i++) {
     auto it = ctx->tapes.find(ids[i]);
     if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
     const DevTape& t = it->second;
-    TapeDesc& d = L->descs[i];
+    const bool strands = (t.hdr.flags & ZKIR_TAPE_F_STRANDS) != 0;
+    Launch& G = L[strands ? 1 : 0];
+    G.descs.emplace_back();
+    TapeDesc& d = G.descs.back();
     std::memset(&d, 0, sizeof d);
     d.ops = (const zkir_op*)t.ops;
     d.consts = (const uint32_t*)t.consts;
@@ -189,8 +193,8 @@ int32_t build_launch(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, uint64_
     d.n_outputs = t.hdr.n_outputs;
     d.n_constraints = t.hdr.n_constraints;
     d.n_consts = t.hdr.n_consts;
-    if (t.hdr.flags & ZKIR_TAPE_F_STRANDS) {
-      L->n_strand_tapes++;
+    d.unsat_index = i;
+    if (strands) {
       d.n_xslots = t.hdr.n_xslots;
       uint32_t begin = 0;
       for (uint32_t s = 0; s < ZKIR_STRANDS; s++) {
@@ -198,13 +202,13 @@ int32_t build_launch(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, uint64_
         d.strand_ops[s] = t.hdr.strand_ops[s];
         begin += t.hdr.strand_ops[s];
       }
-      L->max_xslots = std::max(L->max_xslots, t.hdr.n_xslots);
+      G.max_xslots = std::max(G.max_xslots, t.hdr.n_xslots);
     }
     in_off += (uint64_t)t.hdr.n_inputs * 8 * N;
     out_off += (uint64_t)t.hdr.n_outputs * 8 * N;
-    L->full = L->full || t.full;
-    L->max_gslots = std::max(L->max_gslots, t.hdr.n_gslots);
-    L->max_lslots = std::max(L->max_lslots, t.hdr.n_lslots);
+    G.full = G.full || t.full;
+    G.max_gslots = std::max(G.max_gslots, t.hdr.n_gslots);
+    G.max_lslots = std::max(G.max_lslots, t.hdr.n_lslots);
   }
   return ZKIR_OK;
 }
@@ -215,25 +219,34 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
                   uint32_t* out_dev, uint64_t* unsat_dev, uint64_t* stats_dev, hipStream_t stream) {
   if (N == 0 || n == 0) return ZKIR_OK;
   if (N >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "N must be below 2^32");
-  Launch L;
-  int32_t rc = build_launch(ctx, ids, n, N, &L);
+  Launch L[2];
+  int32_t rc = build_launches(ctx, ids, n, N, L);
   if (rc) return rc;
-  if (L.n_strand_tapes && L.n_strand_tapes != n)
-    return fail(ctx, ZKIR_E_INVALID, "a launch takes strand tapes or plain tapes, not both");
-  const uint32_t strands = L.n_strand_tapes ? 1u : 0u;
-  // a pass is one workgroup's worth of vectors: 256, or 64 when its four wavefronts are the four strands
-  const uint32_t per_pass = strands ? 64u : (uint32_t)ZKIR_BLOCK_THREADS;
-  const uint32_t passes = (uint32_t)((N + per_pass - 1) / per_pass);
-  const uint64_t work = (uint64_t)n * passes;
-  if (work >= (1ull << 32) - (1u << 20)) return fail(ctx, ZKIR_E_LIMIT, "too many (tape, pass) work items for one launch");
-  int variant = pick_variant(L.full, N);
-  if (strands) {  // only the generated stream runs strand tapes (upload refused any other operator)
-    if (N * 32 >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 2^27 vectors per launch");
-    variant = 2;
-  }
-  const uint32_t grid = pick_grid(ctx, work, variant, L.max_lslots, strands, L.max_xslots);
+  struct Plan {
+    int variant;
+    uint32_t strands, passes, grid;
+  } plan[2];
   const size_t slot_bytes = (size_t)2 * ZKIR_BLOCK_THREADS * 16;
-  rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, (size_t)grid * L.max_gslots * slot_bytes);
+  size_t pool_bytes = 0;
+  for (int k = 0; k < 2; k++) {
+    const Launch& G = L[k];
+    if (G.descs.empty()) continue;
+    Plan& P = plan[k];
+    P.strands = (uint32_t)k;
+    // a pass is one workgroup's worth of vectors: 256, or 64 when its four wavefronts are the four strands
+    const uint32_t per_pass = k ? 64u : (uint32_t)ZKIR_BLOCK_THREADS;
+    P.passes = (uint32_t)((N + per_pass - 1) / per_pass);
+    const uint64_t work = (uint64_t)G.descs.size() * P.passes;
+    if (work >= (1ull << 32) - (1u << 20)) return fail(ctx, ZKIR_E_LIMIT, "too many (tape, pass) work items for one launch");
+    P.variant = pick_variant(G.full, N);
+    if (k) {  // only the generated stream runs strand tapes (upload refused any other operator)
+      if (N * 32 >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 2^27 vectors per launch");
+      P.variant = 2;
+    }
+    P.grid = pick_grid(ctx, work, P.variant, G.max_lslots, P.strands, G.max_xslots);
+    pool_bytes = std::max(pool_bytes, (size_t)P.grid * G.max_gslots * slot_bytes);
+  }
+  rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, pool_bytes);
   if (rc) return rc;
   rc = ensure(ctx, &ctx->desc_buf, &ctx->desc_buf_bytes, (size_t)n * sizeof(TapeDesc));
   if (rc) return rc;
@@ -241,15 +254,23 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
     HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->upload_done, 0));
     ctx->upload_pending = false;
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->desc_buf, L.descs.data(), (size_t)n * sizeof(TapeDesc), hipMemcpyHostToDevice, stream));
-  // L.descs is pageable host memory: hipMemcpyAsync has consumed it when it returns,
-  // and the device-side staging buffer is only rewritten by later work on `stream`.
+  // the two launches draw work items from two counters (64 bytes apart) zeroed here
   HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, 256, stream));
-  hipError_t e = zkir::launch_interp(variant, (const TapeDesc*)ctx->desc_buf, n, passes, N, in_dev, out_dev, ctx->gslot_pool,
-                                     L.max_gslots, L.max_lslots, unsat_dev, stats_dev, (uint32_t*)ctx->work_counter,
-                                     grid, strands, L.max_xslots, stream);
-  if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
-  ctx->launched_since_sync = true;
+  size_t desc_at = 0;
+  for (int k = 0; k < 2; k++) {
+    const Launch& G = L[k];
+    if (G.descs.empty()) continue;
+    TapeDesc* descs_dev = (TapeDesc*)ctx->desc_buf + desc_at;
+    // G.descs is pageable host memory: hipMemcpyAsync has consumed it when it returns,
+    // and the device-side staging buffer is only rewritten by later work on `stream`.
+    HIP_TRY(ctx, hipMemcpyAsync(descs_dev, G.descs.data(), G.descs.size() * sizeof(TapeDesc), hipMemcpyHostToDevice, stream));
+    hipError_t e = zkir::launch_interp(plan[k].variant, descs_dev, (uint32_t)G.descs.size(), plan[k].passes, N, in_dev, out_dev,
+                                       ctx->gslot_pool, G.max_gslots, G.max_lslots, unsat_dev, stats_dev,
+                                       (uint32_t*)ctx->work_counter + 16 * k, plan[k].grid, plan[k].strands, G.max_xslots, stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
+    ctx->launched_since_sync = true;
+    desc_at += G.descs.size();
+  }
   return ZKIR_OK;
 }
 
