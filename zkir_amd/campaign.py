@@ -40,14 +40,15 @@ def campaign_config(circuit_id, min_constraints=64, max_constraints=4096):
 
 
 def _lower_one(args):
-    cid, base_seed = args
+    cid, base_seed, lower_options = args
     try:
-        return cid, 0, api.Lowerer(api.Generator(circuit_seed(base_seed, cid), campaign_config(cid)).generate()).lower()
+        circuit = api.Generator(circuit_seed(base_seed, cid), campaign_config(cid)).generate()
+        return cid, 0, api.Lowerer(circuit, lower_options).lower()
     except api.LowerRejected as e:
         return cid, e.status_class, None
 
 
-def lower_parallel(circuit_ids, base_seed, workers=8, window=64):
+def lower_parallel(circuit_ids, base_seed, workers=8, window=64, lower_options=None):
     """Generate and lower campaign circuits on `workers` host threads; yields
     (circuit id, class, Tape or None) in id order.  The library's host functions keep no
     shared state and ctypes drops the interpreter lock around them, so plain threads scale
@@ -58,13 +59,13 @@ def lower_parallel(circuit_ids, base_seed, workers=8, window=64):
     with ThreadPoolExecutor(workers) as ex:
         pending, it = deque(), iter(circuit_ids)
         for cid in it:
-            pending.append(ex.submit(_lower_one, (cid, base_seed)))
+            pending.append(ex.submit(_lower_one, (cid, base_seed, lower_options)))
             if len(pending) >= window * workers:
                 break
         while pending:
             yield pending.popleft().result()
             for cid in it:
-                pending.append(ex.submit(_lower_one, (cid, base_seed)))
+                pending.append(ex.submit(_lower_one, (cid, base_seed, lower_options)))
                 break
 
 
@@ -217,6 +218,9 @@ def main(argv=None):
     ap.add_argument("--group", type=int, default=2048,
                     help="circuits per launch (a launch should hold several times the 1 280 workgroups the GPU runs at once)")
     ap.add_argument("--workers", type=int, default=8, help="host threads that generate and lower, per rank")
+    ap.add_argument("--strands", type=int, default=0, choices=[0, 4],
+                    help="4: ask lower for strand tapes (circuits they do not fit come back as plain tapes); for "
+                         "campaigns whose launches leave the GPU short of wavefronts")
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,8 +237,12 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    lower_options = None
+    if args.strands:
+        lower_options = api.default_lower_options()
+        lower_options.strands = args.strands
     res = run_local(ids, args.seed, args.vectors, ev, group=args.group,
-                    lowered=lower_parallel(ids, args.seed, workers=args.workers))
+                    lowered=lower_parallel(ids, args.seed, workers=args.workers, lower_options=lower_options))
     tot = reduce_results(res, dist if world > 1 else None, device)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
