@@ -114,9 +114,6 @@ int32_t ensure(zkir_ctx* ctx, void** buf, size_t* have, size_t need) {
   return ZKIR_OK;
 }
 
-// Grid: as many workgroups as the machine holds at once (the occupancy the kernel's
-// registers and the LDS window allow), never more than there is work; each workgroup
-// then walks the work items with a grid stride and reuses its slot region.
 // `bytes` of 256-byte-aligned device memory from the tape arena; *slab_out names the slab
 int32_t arena_alloc(zkir_ctx* ctx, size_t bytes, void** out, int* slab_out) {
   const size_t need = (std::max<size_t>(bytes, 256) + 255) & ~(size_t)255;
@@ -143,6 +140,9 @@ int32_t arena_alloc(zkir_ctx* ctx, size_t bytes, void** out, int* slab_out) {
   return ZKIR_OK;
 }
 
+// Grid: as many workgroups as the machine holds at once (the occupancy the kernel's
+// registers and its LDS allow), never more than there is work; workgroups draw work items from a
+// device-wide counter and reuse their slot region from item to item.
 uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, int variant, uint32_t lslots, uint32_t strands,
                    uint32_t xslots) {
   int per_cu = 2;
