@@ -14,7 +14,12 @@
  *     nothing throws or aborts across this boundary;
  *   - the caller owns every buffer it passes; handles are opaque;
  *   - one zkir_ctx per device; a context is not thread-safe, separate
- *     contexts are independent;
+ *     contexts are independent.  The evaluation calls on device pointers are
+ *     asynchronous, and the launches of ONE context share its work counters,
+ *     descriptor buffer and witness-slot pool: the library makes each launch
+ *     wait (hipStreamWaitEvent) for the previous launch of the same context,
+ *     so calls on different streams give the results of serial calls, they
+ *     just do not overlap.  Use one context per stream for overlap;
  *   - field elements crossing the ABI are canonical integers in [0, p) of the
  *     BN254 scalar field, 8 little-endian 32-bit limbs; Montgomery form is
  *     internal to the device code;
@@ -327,7 +332,8 @@ int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hd
  *   first_unsat  nullable; [2] = {vector, constraint} of the unsatisfied pair
  *                with the smallest vector index (then smallest constraint),
  *                0xffffffff each when every constraint holds
- * N < 2^32; a strand tape takes N < 2^27 per launch (ZKIR_E_LIMIT beyond). */
+ * N < 2^32; a strand tape takes N < 2^27 per launch and fewer than 2^19 device slots per
+ * strand (ZKIR_E_LIMIT beyond). */
 int32_t zkir_eval_batch(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa, uint64_t N,
                         uint32_t* outputs_soa, uint64_t* unsat_count, uint32_t* first_unsat);
 
@@ -346,9 +352,12 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
 int32_t zkir_eval_multi(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs,
                         uint64_t N_per_tape, uint64_t* per_tape_unsat);
 
-/* Device-pointer form of zkir_eval_multi; per_tape_unsat_dev [n_tapes] uint64. */
+/* Device-pointer form of zkir_eval_multi; per_tape_unsat_dev [n_tapes] uint64.  result_dev
+ * (nullable) points to 4 uint64 in device memory, initialised by the call:
+ * {0, smallest (vector<<32 | constraint) over the unsatisfied pairs of all tapes or all ones,
+ *  faults (vectors that divided by zero at run time, over all tapes), reserved}. */
 int32_t zkir_eval_multi_dev(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs_dev,
-                            uint64_t N_per_tape, uint64_t* per_tape_unsat_dev, void* stream);
+                            uint64_t N_per_tape, uint64_t* per_tape_unsat_dev, uint64_t* result_dev, void* stream);
 
 /* Faults (division by zero at run time) seen by the last synchronous call. */
 int32_t zkir_last_faults(const zkir_ctx* ctx, uint64_t* faults);

@@ -557,3 +557,127 @@ def test_measured_rates_are_sane(ctx):
     assert 5e12 < mulhi < 6e13
     fr = ctx.fr_mul_rate()
     assert 2e10 < fr < 4e11
+
+
+def test_two_streams_one_context_give_serial_results(ctx):
+    """Launches of one context share its work counters, descriptors and slot pool; the library chains
+    them, so two device-pointer calls issued back to back on two streams give what serial calls give."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    cfg = dict(forced_inputs=6, inputs_readable=1, arithmetic_only=1, quadratic_aware=1, no_loops=1, safe_array_index=1)
+    ta = z.Lowerer(z.Generator(501, ext_config(min_instructions=2500, max_instructions=2500, **cfg)).generate()).lower()
+    tb = z.Lowerer(z.Generator(502, ext_config(min_instructions=900, max_instructions=900, **cfg)).generate()).lower()
+    # tb with a failing constraint planted, so the counts are not all zero
+    ops = tb.ops()
+    j = next(i for i, op in enumerate(ops) if op[0] == F.OP_MUL)
+    ops[j] = (F.OP_ADD,) + ops[j][1:]
+    tb = z.Tape.from_parts(tb.hdr, b"".join(struct.pack("<4I", *op) for op in ops) + tb.blob()[16 * len(ops):])
+    ida, idb = ctx.upload(ta), ctx.upload(tb)
+    na, nb = 150000, 40000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(21)
+
+    def inputs(t, n):
+        a = torch.randint(0, 1 << 32, (t.hdr.n_inputs, 8, n), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+        a[:, 7, :] &= 0x0FFFFFFF
+        return a
+
+    ina, inb = inputs(ta, na), inputs(tb, nb)
+    many = [z.Lowerer(z.Generator(600 + k, ext_config(min_instructions=300, max_instructions=300, **cfg)).generate()).lower()
+            for k in range(40)]
+    mids = ctx.upload_many(many)
+    nm = 512
+    inm = torch.randint(0, 1 << 32, (sum(t.hdr.n_inputs for t in many), 8, nm), dtype=torch.int64, device=dev,
+                        generator=gen).to(torch.int32)
+    inm[:, 7, :] &= 0x0FFFFFFF
+
+    def run(streams):
+        oa = torch.zeros((ta.hdr.n_outputs, 8, na), dtype=torch.int32, device=dev)
+        ob = torch.zeros((tb.hdr.n_outputs, 8, nb), dtype=torch.int32, device=dev)
+        ra, rb, rm = (torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(3))
+        um = torch.zeros(len(many), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        ctx.eval_batch_dev(ida, ina.data_ptr(), na, oa.data_ptr(), ra.data_ptr(), streams[0].cuda_stream)
+        ctx.eval_batch_dev(idb, inb.data_ptr(), nb, ob.data_ptr(), rb.data_ptr(), streams[1].cuda_stream)
+        ctx.eval_multi_dev(mids, inm.data_ptr(), nm, um.data_ptr(), streams[2].cuda_stream, rm.data_ptr())
+        ctx.eval_batch_dev(ida, ina.data_ptr(), na, oa.data_ptr(), ra.data_ptr(), streams[1].cuda_stream)
+        torch.cuda.synchronize()
+        return oa.cpu(), ob.cpu(), ra.cpu(), rb.cpu(), um.cpu(), rm.cpu()
+
+    s0 = torch.cuda.current_stream()
+    serial = run([s0, s0, s0])
+    side = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    overlapped = run(side)
+    for a, b in zip(serial, overlapped):
+        assert torch.equal(a, b)
+    assert int(serial[2][0]) == 0 and int(serial[3][0]) > 0 and int(serial[4].sum()) == 0
+    # sampled vectors of the first call against the checker
+    idx = [0, 1, 77777, na - 1]
+    inp_s = np.ascontiguousarray(ina[:, :, idx].cpu().numpy().view(np.uint32))
+    o_c, _, _, _ = C.eval_cpu(bytes(ta.hdr), ta.blob(), inp_s, len(idx), ta.hdr.n_outputs)
+    assert np.array_equal(np.ascontiguousarray(overlapped[0][:, :, idx].numpy().view(np.uint32)), o_c)
+    for t in [ida, idb] + mids:
+        ctx.release(t)
+
+
+def test_run_time_faults_of_a_multi_tape_launch_reach_the_caller(ctx):
+    """Division by a run-time zero in some vectors of some tapes of one device-pointer launch: the fault
+    count comes back in the caller's result words (and through the campaign's evaluator)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    div = hand_tape([(F.OP_INPUT, G(0), I(0), NONE), (F.OP_INPUT, G(1), I(1), NONE), (F.OP_DIV, G(2), G(0), G(1)),
+                     (F.OP_OUTPUT, 0, G(2), NONE)], [], 2, 1, 3, 0)
+    rem = hand_tape([(F.OP_INPUT, G(0), I(0), NONE), (F.OP_INPUT, G(1), I(1), NONE), (F.OP_REM, G(2), G(0), G(1)),
+                     (F.OP_MUL, G(3), G(2), G(0)), (F.OP_CHECK, G(3), G(2), G(0))], [], 2, 0, 4, 0)
+    clean = z.Lowerer(z.Generator(9, ext_config(min_instructions=120, max_instructions=120, forced_inputs=2, inputs_readable=1,
+                                                 arithmetic_only=1, quadratic_aware=1, no_loops=1, safe_array_index=1)).generate()).lower()
+    tapes = [clean, div, clean, rem, div]
+    n = 700
+    rnd = random.Random(31)
+    blocks, want_faults = [], 0
+    for t in tapes:
+        vecs = random_vectors(rnd, t.hdr.n_inputs, n, special_share=0.0)
+        if t is not clean:
+            for k in rnd.sample(range(n), 9):
+                vecs[k][1] = 0
+        inp = z.pack_inputs(vecs, t.hdr.n_inputs)
+        _, _, _, f_c = C.eval_cpu(bytes(t.hdr), t.blob(), inp, n, t.hdr.n_outputs, want_outputs=False)
+        want_faults += f_c
+        blocks.append(inp.reshape(-1))
+    assert want_faults == 27
+    tids = ctx.upload_many(tapes)
+    inp = torch.from_numpy(np.concatenate(blocks).view(np.int32)).to(dev)
+    unsat = torch.zeros(len(tapes), dtype=torch.int64, device=dev)
+    res = torch.full((4,), 5, dtype=torch.int64, device=dev)
+    ctx.eval_multi_dev(tids, inp.data_ptr(), n, unsat.data_ptr(), torch.cuda.current_stream().cuda_stream, res.data_ptr())
+    torch.cuda.synchronize()
+    r = res.cpu().numpy().view(np.uint64)
+    assert int(r[2]) == want_faults and int(r[0]) == 0 and int(unsat.sum()) == 0
+    # the host-pointer form reports the same count
+    _, faults = ctx.eval_multi(tids, np.concatenate(blocks), n)
+    assert faults == want_faults
+    for t in tids:
+        ctx.release(t)
+    # and the campaign's evaluator no longer drops them: draws are random, so plant a zero divisor as a constant
+    from zkir_amd import campaign
+    ev = campaign.GpuEvaluator(0, input_seed=3)
+    zero_div = hand_tape([(F.OP_INPUT, G(0), I(0), NONE), (F.OP_IDIV, G(1), G(0), K(0)), (F.OP_OUTPUT, 0, G(1), NONE)],
+                         [0], 1, 1, 2, 0)
+    got_unsat, got_faults = ev([clean, zero_div], 300, [0, 1])
+    assert got_unsat == [0, 0] and got_faults == 300
+    ev.close()
+
+
+def test_tape_with_more_device_slots_than_the_generated_stream_addresses(ctx):
+    """8 KiB x n_gslots no longer fits the 32-bit offsets of the generated stream: the launch takes the
+    compiled kernel (64-bit addresses) and the far slots hold what was put there."""
+    torch = pytest.importorskip("torch")
+    far = (1 << 19) + 2  # slot rows of 8 KiB: the last one sits past 4 GiB in the workgroup's region
+    ops = [(F.OP_INPUT, G(far), I(0), NONE), (F.OP_INPUT, G(1), I(1), NONE), (F.OP_MUL, G(far - 1), G(far), G(1)),
+           (F.OP_ADD, G(2), G(far - 1), G(far)), (F.OP_OUTPUT, 0, G(2), NONE), (F.OP_OUTPUT, 1, G(far), NONE),
+           (F.OP_CHECK, G(far - 1), G(1), G(far))]
+    tape = hand_tape(ops, [], 2, 2, far + 1, 0)
+    vecs = random_vectors(random.Random(8), 2, 200)
+    out, unsat, _, _ = check_against_c_oracle(ctx, tape, vecs)
+    assert unsat == 0 and z.unpack_outputs(out[:, :, 5:6])[0] == [F.add(F.mul(vecs[5][0], vecs[5][1]), vecs[5][0]), vecs[5][0]]
+    torch.cuda.empty_cache()

@@ -91,7 +91,7 @@ def _load():
         "zkir_eval_batch": [c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, P(c_uint64), P(c_uint32)],
         "zkir_eval_batch_dev": [c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p],
         "zkir_eval_multi": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, P(c_uint64)],
-        "zkir_eval_multi_dev": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, c_void_p, c_void_p],
+        "zkir_eval_multi_dev": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p],
         "zkir_last_faults": [c_void_p, P(c_uint64)],
         "zkir_measure_int_mul_rate": [c_void_p, c_int32, P(c_double)],
         "zkir_measure_fr_mul_rate": [c_void_p, P(c_double)],
@@ -380,9 +380,10 @@ class Context:
         self._check(lib.zkir_last_faults(self._h, byref(faults)))
         return [unsat[i] for i in range(len(tids))], faults.value
 
-    def eval_multi_dev(self, tids, inputs_ptr, n_per_tape, unsat_ptr, stream=None):
+    def eval_multi_dev(self, tids, inputs_ptr, n_per_tape, unsat_ptr, stream=None, result_ptr=None):
+        """result_ptr: None, or 4 uint64 of device memory for {0, first unsat pair, faults, reserved}."""
         ids = (c_uint32 * len(tids))(*tids)
-        self._check(lib.zkir_eval_multi_dev(self._h, ids, len(tids), inputs_ptr, n_per_tape, unsat_ptr, stream))
+        self._check(lib.zkir_eval_multi_dev(self._h, ids, len(tids), inputs_ptr, n_per_tape, unsat_ptr, result_ptr, stream))
 
     def int_mul_rate(self, which):
         d = c_double()
@@ -393,3 +394,4 @@ class Context:
         d = c_double()
         self._check(lib.zkir_measure_fr_mul_rate(self._h, byref(d)))
         return d.value
+

@@ -161,12 +161,13 @@ class GpuEvaluator:
         if words:
             inp[:words].view(-1, 8, n_vectors)[:, 7, :] &= 0x0FFFFFFF
         unsat = torch.zeros(len(tapes), dtype=torch.int64, device=self.device)
+        result = torch.zeros(4, dtype=torch.int64, device=self.device)  # {0, first unsat pair, faults, reserved}
         stream = torch.cuda.current_stream().cuda_stream
-        self.ctx.eval_multi_dev(tids, inp.data_ptr(), n_vectors, unsat.data_ptr(), stream)
+        self.ctx.eval_multi_dev(tids, inp.data_ptr(), n_vectors, unsat.data_ptr(), stream, result.data_ptr())
         torch.cuda.synchronize()
         for tid in tids:
             self.ctx.release(tid)
-        return [int(v) for v in unsat.cpu()], 0
+        return [int(v) for v in unsat.cpu()], int(result[2].item())
 
     def close(self):
         self.ctx.close()

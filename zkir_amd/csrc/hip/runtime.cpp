@@ -35,7 +35,8 @@ struct DevTape {
   bool full = false;       // uses an operator beyond + - * : needs the full interpreter
   void* ops = nullptr;     // device
   void* consts = nullptr;  // device, Montgomery form
-  int slab = -1;           // which slab of the context's tape arena holds ops and consts
+  void* desc = nullptr;    // device: the TapeDesc of this tape evaluated alone (offsets 0, unsat index 0)
+  int slab = -1;           // which slab of the context's tape arena holds ops, consts and desc
 };
 
 // Device memory for uploaded tapes: slabs with bump allocation, so that an upload costs one
@@ -73,8 +74,19 @@ struct zkir_ctx {
   void* pipe_stage[2] = {nullptr, nullptr};  // pinned host memory: a piece of the result on its way to the caller
   std::vector<TapeSlab> slabs;
   hipEvent_t upload_done = nullptr;  // recorded after the latest upload's device work
-  bool upload_pending = false;       // an evaluation on another stream must wait for upload_done
+  bool upload_pending = false;       // evaluations must wait for upload_done (until the device has been synchronised)
   bool launched_since_sync = false;  // a launch may still be reading tapes: release must wait for the device
+  // Launches of one context share its work counters, descriptor buffer and slot pool, so they run one
+  // after the other whatever streams the caller uses: every launch waits for launch_done of the one before.
+  hipEvent_t launch_done = nullptr;
+  bool launch_recorded = false;
+  // descriptors of a multi-tape call travel through pinned host memory the context owns (two buffers in
+  // turn; a buffer is rewritten only after the copy that read it has finished)
+  void* desc_stage[2] = {nullptr, nullptr};
+  size_t desc_stage_bytes[2] = {0, 0};
+  hipEvent_t desc_copied[2] = {nullptr, nullptr};
+  bool desc_copy_recorded[2] = {false, false};
+  int desc_turn = 0;
 };
 
 namespace {
@@ -114,14 +126,16 @@ int32_t ensure(zkir_ctx* ctx, void** buf, size_t* have, size_t need) {
   return ZKIR_OK;
 }
 
-// `bytes` of 256-byte-aligned device memory from the tape arena; *slab_out names the slab
-int32_t arena_alloc(zkir_ctx* ctx, size_t bytes, void** out, int* slab_out) {
+// `bytes` of 256-byte-aligned device memory from the tape arena; *slab_out names the slab,
+// *mark_out what arena_rollback needs to give the bytes back
+int32_t arena_alloc(zkir_ctx* ctx, size_t bytes, void** out, int* slab_out, size_t* mark_out) {
   const size_t need = (std::max<size_t>(bytes, 256) + 255) & ~(size_t)255;
   for (size_t i = 0; i < ctx->slabs.size(); i++) {
     TapeSlab& sl = ctx->slabs[i];
     if (sl.live == 0) sl.used = 0;  // everything in it was released
     if (sl.size - sl.used >= need) {
       *out = sl.base + sl.used;
+      *mark_out = sl.used;
       sl.used += need;
       sl.live++;
       *slab_out = (int)i;
@@ -135,9 +149,58 @@ int32_t arena_alloc(zkir_ctx* ctx, size_t bytes, void** out, int* slab_out) {
   sl.used = need;
   sl.live = 1;
   *out = sl.base;
-  ctx->slabs.push_back(sl);
+  *mark_out = 0;
+  try {
+    ctx->slabs.push_back(sl);
+  } catch (const std::bad_alloc&) {
+    (void)hipFree(sl.base);
+    return fail(ctx, ZKIR_E_NOMEM, "tape arena bookkeeping");
+  }
   *slab_out = (int)ctx->slabs.size() - 1;
   return ZKIR_OK;
+}
+
+// an upload failed after arena_alloc: the bytes go back when nothing was allocated behind them
+void arena_rollback(zkir_ctx* ctx, int slab, size_t mark, size_t bytes) {
+  TapeSlab& sl = ctx->slabs[slab];
+  const size_t need = (std::max<size_t>(bytes, 256) + 255) & ~(size_t)255;
+  sl.live--;
+  if (sl.used == mark + need) sl.used = mark;
+}
+
+// does the tape use an operator beyond + - * (it then needs the kernel that knows every operator)
+bool tape_is_full(const zkir_tape_hdr& h, const void* blob) {
+  for (uint32_t i = 0; i < h.n_ops; i++) {
+    const uint32_t c = ((const zkir_op*)blob)[i].code & 0xffu;
+    if (c == ZKIR_OP_BNOT || c == ZKIR_OP_BNOT256 || (c >= ZKIR_OP_POW && c <= ZKIR_OP_SHL)) return true;
+  }
+  return false;
+}
+
+// descriptor of tape `t` at place `index` of a call whose blocks start at the given word offsets
+TapeDesc make_desc(const DevTape& t, uint32_t index, uint64_t in_off, uint64_t out_off) {
+  TapeDesc d;
+  std::memset(&d, 0, sizeof d);
+  d.ops = (const zkir_op*)t.ops;
+  d.consts = (const uint32_t*)t.consts;
+  d.in_word_off = in_off;
+  d.out_word_off = out_off;
+  d.n_ops = t.hdr.n_ops;
+  d.n_inputs = t.hdr.n_inputs;
+  d.n_outputs = t.hdr.n_outputs;
+  d.n_constraints = t.hdr.n_constraints;
+  d.n_consts = t.hdr.n_consts;
+  d.unsat_index = index;
+  if (t.hdr.flags & ZKIR_TAPE_F_STRANDS) {
+    d.n_xslots = t.hdr.n_xslots;
+    uint32_t begin = 0;
+    for (uint32_t s = 0; s < ZKIR_STRANDS; s++) {
+      d.strand_begin[s] = begin;
+      d.strand_ops[s] = t.hdr.strand_ops[s];
+      begin += t.hdr.strand_ops[s];
+    }
+  }
+  return d;
 }
 
 // Grid: as many workgroups as the machine holds at once (the occupancy the kernel's
@@ -153,125 +216,209 @@ uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, int variant, uint32
   return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, work_items));
 }
 
+constexpr size_t kSlotBytes = (size_t)2 * ZKIR_BLOCK_THREADS * 16;  // one witness slot of one workgroup: 8 KiB
+
 // Which interpreter kernel runs a launch: 1 (compiled, every operator) when a tape uses an
-// operator beyond + - *; otherwise 2, the generated instruction stream, which needs 32*N to
-// fit 32 bits; otherwise 0, the compiled + - * kernel.  ZKIR_INTERP=compiled in the
+// operator beyond + - *; otherwise 2, the generated instruction stream, which addresses a
+// vector's data and a workgroup's slot region in 32 bits (32*N and 8192*gslots below 2^32);
+// otherwise 0, the compiled + - * kernel.  ZKIR_INTERP=compiled in the
 // environment forces the compiled kernels (a debugging aid: all three give the same bits).
-int pick_variant(bool full, uint64_t N) {
+int pick_variant(bool full, uint64_t N, uint32_t max_gslots) {
   if (full) return 1;
   const char* want = std::getenv("ZKIR_INTERP");
   if (want && std::strcmp(want, "compiled") == 0) return 0;
-  return N * 32 < (1ull << 32) ? 2 : 0;
+  return (N * 32 < (1ull << 32) && (uint64_t)max_gslots * kSlotBytes < (1ull << 32)) ? 2 : 0;
 }
 
-// The tapes of one call, split by kind: plain tapes run 256 vectors per workgroup, strand tapes 64 (their
+// The tapes of one kind in a call: plain tapes run 256 vectors per workgroup, strand tapes 64 (their
 // four wavefronts are the four strands), so a call that holds both becomes two launches on the same
-// stream.  Input / output offsets and the unsat index of a tape are those of its place in the call.
-struct Launch {
-  std::vector<TapeDesc> descs;
+// stream.
+struct Group {
+  uint32_t count = 0;
   bool full = false;
   uint32_t max_gslots = 0, max_lslots = 0, max_xslots = 0;
+  void add(const DevTape& t) {
+    count++;
+    full = full || t.full;
+    max_gslots = std::max(max_gslots, t.hdr.n_gslots);
+    max_lslots = std::max(max_lslots, t.hdr.n_lslots);
+    if (t.hdr.flags & ZKIR_TAPE_F_STRANDS) max_xslots = std::max(max_xslots, t.hdr.n_xslots);
+  }
+};
+struct Plan {
+  int variant = 0;
+  uint32_t strands = 0, passes = 0, grid = 0;
 };
 
-int32_t build_launches(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, uint64_t N, Launch L[2]) {
-  uint64_t in_off = 0, out_off = 0;
-  for (uint32_t i = 0; i < n; i++) {
-    auto it = ctx->tapes.find(ids[i]);
-    if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
-    const DevTape& t = it->second;
-    const bool strands = (t.hdr.flags & ZKIR_TAPE_F_STRANDS) != 0;
-    Launch& G = L[strands ? 1 : 0];
-    G.descs.emplace_back();
-    TapeDesc& d = G.descs.back();
-    std::memset(&d, 0, sizeof d);
-    d.ops = (const zkir_op*)t.ops;
-    d.consts = (const uint32_t*)t.consts;
-    d.in_word_off = in_off;
-    d.out_word_off = out_off;
-    d.n_ops = t.hdr.n_ops;
-    d.n_inputs = t.hdr.n_inputs;
-    d.n_outputs = t.hdr.n_outputs;
-    d.n_constraints = t.hdr.n_constraints;
-    d.n_consts = t.hdr.n_consts;
-    d.unsat_index = i;
-    if (strands) {
-      d.n_xslots = t.hdr.n_xslots;
-      uint32_t begin = 0;
-      for (uint32_t s = 0; s < ZKIR_STRANDS; s++) {
-        d.strand_begin[s] = begin;
-        d.strand_ops[s] = t.hdr.strand_ops[s];
-        begin += t.hdr.strand_ops[s];
-      }
-      G.max_xslots = std::max(G.max_xslots, t.hdr.n_xslots);
-    }
-    in_off += (uint64_t)t.hdr.n_inputs * 8 * N;
-    out_off += (uint64_t)t.hdr.n_outputs * 8 * N;
-    G.full = G.full || t.full;
-    G.max_gslots = std::max(G.max_gslots, t.hdr.n_gslots);
-    G.max_lslots = std::max(G.max_lslots, t.hdr.n_lslots);
+// pool_rows_cap: 0, or the slot rows (8 KiB each) the caller's fixed pool holds; the grid shrinks to fit
+int32_t plan_group(zkir_ctx* ctx, const Group& G, int kind, uint64_t N, size_t pool_rows_cap, Plan* P) {
+  P->strands = (uint32_t)kind;
+  // a pass is one workgroup's worth of vectors: 256, or 64 when its four wavefronts are the four strands
+  const uint32_t per_pass = kind ? 64u : (uint32_t)ZKIR_BLOCK_THREADS;
+  P->passes = (uint32_t)((N + per_pass - 1) / per_pass);
+  const uint64_t work = (uint64_t)G.count * P->passes;
+  if (work >= (1ull << 32) - (1u << 20)) return fail(ctx, ZKIR_E_LIMIT, "too many (tape, pass) work items for one launch");
+  P->variant = pick_variant(G.full, N, G.max_gslots);
+  if (kind) {  // only the generated stream runs strand tapes (upload refused any other operator)
+    if (N * 32 >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 2^27 vectors per launch");
+    if ((uint64_t)G.max_gslots * kSlotBytes >= (1ull << 32))
+      return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 2^19 device slots per strand");
+    P->variant = 2;
+  }
+  P->grid = pick_grid(ctx, work, P->variant, G.max_lslots, P->strands, G.max_xslots);
+  if (pool_rows_cap && G.max_gslots) {
+    if (G.max_gslots > pool_rows_cap)
+      return fail(ctx, ZKIR_E_LIMIT, "the tape needs " + std::to_string(G.max_gslots) + " device slots; the fixed scratch holds " +
+                                         std::to_string(pool_rows_cap));
+    P->grid = (uint32_t)std::min<uint64_t>(P->grid, pool_rows_cap / G.max_gslots);
   }
   return ZKIR_OK;
 }
 
-// Launch the interpreter on device buffers.  unsat_dev has n entries, stats_dev 2
-// entries ({packed first unsat, faults}); both must already be initialised.
+// what every launch of a context does first on its stream: wait for the constants of fresh uploads and for
+// the launch before it (which may be on another stream and shares the counters, descriptors and slots)
+int32_t chain_stream(zkir_ctx* ctx, hipStream_t stream) {
+  if (ctx->upload_pending) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->upload_done, 0));
+  if (ctx->launch_recorded) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->launch_done, 0));
+  return ZKIR_OK;
+}
+int32_t chain_done(zkir_ctx* ctx, hipStream_t stream) {
+  HIP_TRY(ctx, hipEventRecord(ctx->launch_done, stream));
+  ctx->launch_recorded = true;
+  ctx->launched_since_sync = true;
+  return ZKIR_OK;
+}
+// the device has been synchronised: nothing is in flight any more
+void note_device_idle(zkir_ctx* ctx) {
+  ctx->upload_pending = false;
+  ctx->launched_since_sync = false;
+  ctx->launch_recorded = false;
+}
+
+int32_t launch_group(zkir_ctx* ctx, const Group& G, const Plan& P, const TapeDesc* descs_dev, const uint32_t* in_dev, uint64_t N,
+                     uint32_t* out_dev, void* pool, uint32_t* counter, uint64_t* unsat_dev, uint64_t* stats_dev,
+                     hipStream_t stream) {
+  hipError_t e = zkir::launch_interp(P.variant, descs_dev, G.count, P.passes, N, in_dev, out_dev, pool, G.max_gslots,
+                                     G.max_lslots, unsat_dev, stats_dev, counter, P.grid, P.strands, G.max_xslots, stream);
+  if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
+  return ZKIR_OK;
+}
+
+// One tape on device buffers.  unsat_dev has 1 entry, stats_dev 2 ({packed first unsat, faults}); both
+// must already be initialised.  The tape's own descriptor (written at upload) is used, so nothing is
+// copied.  fixed_scratch: null (the context's growable pool and counters) or a fixed region of
+// `fixed_bytes` whose first 8 KiB hold the work counter and the rest slot rows; with it the call
+// allocates nothing.
+int32_t run_one(zkir_ctx* ctx, const DevTape& t, const uint32_t* in_dev, uint64_t N, uint32_t* out_dev, uint64_t* unsat_dev,
+                uint64_t* stats_dev, hipStream_t stream, unsigned char* fixed_scratch, size_t fixed_bytes) {
+  if (N == 0) return ZKIR_OK;
+  if (N >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "N must be below 2^32");
+  Group G;
+  G.add(t);
+  Plan P;
+  const int kind = (t.hdr.flags & ZKIR_TAPE_F_STRANDS) ? 1 : 0;
+  const size_t rows_cap = fixed_scratch ? (fixed_bytes - kSlotBytes) / kSlotBytes : 0;
+  int32_t rc = plan_group(ctx, G, kind, N, rows_cap, &P);
+  if (rc) return rc;
+  void* pool = nullptr;
+  uint32_t* counter = nullptr;
+  if (fixed_scratch) {
+    counter = (uint32_t*)fixed_scratch;
+    pool = fixed_scratch + kSlotBytes;
+  } else {
+    rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, (size_t)P.grid * G.max_gslots * kSlotBytes);
+    if (rc) return rc;
+    counter = (uint32_t*)ctx->work_counter;
+    pool = ctx->gslot_pool;
+  }
+  rc = chain_stream(ctx, stream);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(counter, 0, 256, stream));
+  rc = launch_group(ctx, G, P, (const TapeDesc*)t.desc, in_dev, N, out_dev, pool, counter, unsat_dev, stats_dev, stream);
+  if (rc) return rc;
+  return chain_done(ctx, stream);
+}
+
+// pinned staging for `bytes` of descriptors; the buffer returned is free to be written
+int32_t desc_stage_acquire(zkir_ctx* ctx, size_t bytes, int* which) {
+  const int k = ctx->desc_turn;
+  ctx->desc_turn ^= 1;
+  if (!ctx->desc_copied[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->desc_copied[k], hipEventDisableTiming));
+  if (ctx->desc_copy_recorded[k]) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->desc_copied[k]));
+    ctx->desc_copy_recorded[k] = false;
+  }
+  if (ctx->desc_stage_bytes[k] < bytes) {
+    if (ctx->desc_stage[k]) HIP_TRY(ctx, hipHostFree(ctx->desc_stage[k]));
+    ctx->desc_stage[k] = nullptr;
+    ctx->desc_stage_bytes[k] = 0;
+    const size_t sz = std::max<size_t>(bytes + bytes / 2, (size_t)64 << 10);
+    if (hipHostMalloc(&ctx->desc_stage[k], sz, hipHostMallocDefault) != hipSuccess)
+      return fail(ctx, ZKIR_E_NOMEM, "pinned descriptor staging buffer");
+    ctx->desc_stage_bytes[k] = sz;
+  }
+  *which = k;
+  return ZKIR_OK;
+}
+
+// Launch the interpreter on device buffers for the tapes of a call.  unsat_dev has n entries, stats_dev 2
+// entries ({packed first unsat, faults}); both must already be initialised.  Input / output offsets and
+// the unsat index of a tape are those of its place in the call.
 int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint32_t* in_dev, uint64_t N,
                   uint32_t* out_dev, uint64_t* unsat_dev, uint64_t* stats_dev, hipStream_t stream) {
   if (N == 0 || n == 0) return ZKIR_OK;
   if (N >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "N must be below 2^32");
-  Launch L[2];
-  int32_t rc = build_launches(ctx, ids, n, N, L);
+  Group G[2];
+  // descriptors in call order, plain tapes from the front, strand tapes from the back of one pinned buffer
+  int stage = 0;
+  int32_t rc = desc_stage_acquire(ctx, (size_t)n * sizeof(TapeDesc), &stage);
   if (rc) return rc;
-  struct Plan {
-    int variant;
-    uint32_t strands, passes, grid;
-  } plan[2];
-  const size_t slot_bytes = (size_t)2 * ZKIR_BLOCK_THREADS * 16;
+  TapeDesc* host_descs = (TapeDesc*)ctx->desc_stage[stage];
+  uint32_t n_strand = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    auto it = ctx->tapes.find(ids[i]);
+    if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
+    if (it->second.hdr.flags & ZKIR_TAPE_F_STRANDS) n_strand++;
+  }
+  uint64_t in_off = 0, out_off = 0;
+  uint32_t at[2] = {0, n - n_strand};
+  for (uint32_t i = 0; i < n; i++) {
+    const DevTape& t = ctx->tapes.find(ids[i])->second;
+    const int kind = (t.hdr.flags & ZKIR_TAPE_F_STRANDS) ? 1 : 0;
+    G[kind].add(t);
+    host_descs[at[kind]++] = make_desc(t, i, in_off, out_off);
+    in_off += (uint64_t)t.hdr.n_inputs * 8 * N;
+    out_off += (uint64_t)t.hdr.n_outputs * 8 * N;
+  }
+  Plan plan[2];
   size_t pool_bytes = 0;
   for (int k = 0; k < 2; k++) {
-    const Launch& G = L[k];
-    if (G.descs.empty()) continue;
-    Plan& P = plan[k];
-    P.strands = (uint32_t)k;
-    // a pass is one workgroup's worth of vectors: 256, or 64 when its four wavefronts are the four strands
-    const uint32_t per_pass = k ? 64u : (uint32_t)ZKIR_BLOCK_THREADS;
-    P.passes = (uint32_t)((N + per_pass - 1) / per_pass);
-    const uint64_t work = (uint64_t)G.descs.size() * P.passes;
-    if (work >= (1ull << 32) - (1u << 20)) return fail(ctx, ZKIR_E_LIMIT, "too many (tape, pass) work items for one launch");
-    P.variant = pick_variant(G.full, N);
-    if (k) {  // only the generated stream runs strand tapes (upload refused any other operator)
-      if (N * 32 >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 2^27 vectors per launch");
-      P.variant = 2;
-    }
-    P.grid = pick_grid(ctx, work, P.variant, G.max_lslots, P.strands, G.max_xslots);
-    pool_bytes = std::max(pool_bytes, (size_t)P.grid * G.max_gslots * slot_bytes);
+    if (!G[k].count) continue;
+    rc = plan_group(ctx, G[k], k, N, 0, &plan[k]);
+    if (rc) return rc;
+    pool_bytes = std::max(pool_bytes, (size_t)plan[k].grid * G[k].max_gslots * kSlotBytes);
   }
   rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, pool_bytes);
   if (rc) return rc;
   rc = ensure(ctx, &ctx->desc_buf, &ctx->desc_buf_bytes, (size_t)n * sizeof(TapeDesc));
   if (rc) return rc;
-  if (ctx->upload_pending) {  // constants of freshly uploaded tapes are converted on the null stream
-    HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->upload_done, 0));
-    ctx->upload_pending = false;
-  }
+  rc = chain_stream(ctx, stream);
+  if (rc) return rc;
   // the two launches draw work items from two counters (64 bytes apart) zeroed here
   HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, 256, stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->desc_buf, host_descs, (size_t)n * sizeof(TapeDesc), hipMemcpyHostToDevice, stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->desc_copied[stage], stream));
+  ctx->desc_copy_recorded[stage] = true;
   size_t desc_at = 0;
   for (int k = 0; k < 2; k++) {
-    const Launch& G = L[k];
-    if (G.descs.empty()) continue;
-    TapeDesc* descs_dev = (TapeDesc*)ctx->desc_buf + desc_at;
-    // G.descs is pageable host memory: hipMemcpyAsync has consumed it when it returns,
-    // and the device-side staging buffer is only rewritten by later work on `stream`.
-    HIP_TRY(ctx, hipMemcpyAsync(descs_dev, G.descs.data(), G.descs.size() * sizeof(TapeDesc), hipMemcpyHostToDevice, stream));
-    hipError_t e = zkir::launch_interp(plan[k].variant, descs_dev, (uint32_t)G.descs.size(), plan[k].passes, N, in_dev, out_dev,
-                                       ctx->gslot_pool, G.max_gslots, G.max_lslots, unsat_dev, stats_dev,
-                                       (uint32_t*)ctx->work_counter + 16 * k, plan[k].grid, plan[k].strands, G.max_xslots, stream);
-    if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
+    if (!G[k].count) continue;
+    rc = launch_group(ctx, G[k], plan[k], (const TapeDesc*)ctx->desc_buf + desc_at, in_dev, N, out_dev, ctx->gslot_pool,
+                      (uint32_t*)ctx->work_counter + 16 * k, unsat_dev, stats_dev, stream);
+    if (rc) return rc;
     ctx->launched_since_sync = true;
-    desc_at += G.descs.size();
+    desc_at += G[k].count;
   }
-  return ZKIR_OK;
+  return chain_done(ctx, stream);
 }
 
 }  // namespace
@@ -293,9 +440,12 @@ int32_t zkir_ctx_create(int32_t device, zkir_ctx** out) {
   ctx->n_cu = prop.multiProcessorCount;
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->result_buf, 4 * sizeof(uint64_t)) != hipSuccess ||
       hipMalloc(&ctx->work_counter, 256) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->upload_done, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->upload_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->launch_done, hipEventDisableTiming) != hipSuccess) {
     if (ctx->result_buf) (void)hipFree(ctx->result_buf);
     if (ctx->work_counter) (void)hipFree(ctx->work_counter);
+    if (ctx->upload_done) (void)hipEventDestroy(ctx->upload_done);
+    if (ctx->launch_done) (void)hipEventDestroy(ctx->launch_done);
     delete ctx;
     return ZKIR_E_HIP;
   }
@@ -309,6 +459,11 @@ int32_t zkir_ctx_destroy(zkir_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (TapeSlab& sl : ctx->slabs) (void)hipFree(sl.base);
   if (ctx->upload_done) (void)hipEventDestroy(ctx->upload_done);
+  if (ctx->launch_done) (void)hipEventDestroy(ctx->launch_done);
+  for (hipEvent_t ev : ctx->desc_copied)
+    if (ev) (void)hipEventDestroy(ev);
+  for (void* b : ctx->desc_stage)
+    if (b) (void)hipHostFree(b);
   void* bufs[] = {ctx->gslot_pool, ctx->desc_buf, ctx->result_buf, ctx->work_counter, ctx->io_in, ctx->io_out, ctx->io_unsat};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -325,37 +480,8 @@ const char* zkir_last_error(const zkir_ctx* ctx) { return ctx ? ctx->err.c_str()
 
 int32_t zkir_tape_upload(zkir_ctx* ctx, const zkir_tape_hdr* hdr, const void* blob, size_t bytes, zkir_tape_id* out) {
   if (!ctx || !hdr || !out) return ZKIR_E_INVALID;
-  std::string why;
-  if (!zkir::check_tape(*hdr, blob, bytes, &why)) return fail(ctx, ZKIR_E_INVALID, "bad tape: " + why);
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  DevTape t;
-  t.hdr = *hdr;
-  for (uint32_t i = 0; i < hdr->n_ops; i++) {
-    const uint32_t c = ((const zkir_op*)blob)[i].code & 0xffu;
-    if (c == ZKIR_OP_BNOT || c == ZKIR_OP_BNOT256 || (c >= ZKIR_OP_POW && c <= ZKIR_OP_SHL)) t.full = true;
-  }
-  if (t.full && (hdr->flags & ZKIR_TAPE_F_STRANDS))
-    return fail(ctx, ZKIR_E_INVALID, "bad tape: strand tapes are made of + - * and data movement only");
-  // ops and constants are adjacent in the blob and stay adjacent on the device: one copy
-  const size_t ops_bytes = (size_t)hdr->n_ops * sizeof(zkir_op);
-  const size_t consts_bytes = (size_t)hdr->n_consts * 32;
-  void* base = nullptr;
-  int32_t rc = arena_alloc(ctx, ops_bytes + consts_bytes, &base, &t.slab);
-  if (rc) return rc;
-  t.ops = base;
-  t.consts = (char*)base + ops_bytes;
-  hipError_t e = hipSuccess;
-  if (ops_bytes + consts_bytes) e = hipMemcpy(base, blob, ops_bytes + consts_bytes, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = zkir::launch_consts_to_mont((uint32_t*)t.consts, hdr->n_consts, nullptr);
-  if (e == hipSuccess) e = hipEventRecord(ctx->upload_done, nullptr);
-  if (e != hipSuccess) {
-    ctx->slabs[t.slab].live--;
-    return hip_fail(ctx, e, "tape upload");
-  }
-  ctx->upload_pending = true;
-  *out = ctx->next_id++;
-  ctx->tapes[*out] = t;
-  return ZKIR_OK;
+  const void* blobs[1] = {blob};
+  return zkir_tape_upload_many(ctx, 1, hdr, blobs, &bytes, out);
 }
 
 int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hdrs, const void* const* blobs,
@@ -363,19 +489,22 @@ int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hd
   if (!ctx || (n && (!hdrs || !blobs || !bytes || !out))) return ZKIR_E_INVALID;
   if (n == 0) return ZKIR_OK;
   std::string why;
-  // device layout of the batch: every tape's ops, then (256-byte aligned) every tape's constants,
-  // so that one kernel converts all constants
-  std::vector<DevTape> tapes(n);
+  // device layout of the batch: every tape's ops, then (256-byte aligned) every tape's constants, so that
+  // one kernel converts all constants, then (256-byte aligned) one descriptor per tape: the tape evaluated alone
+  std::vector<DevTape> tapes;
+  std::vector<char> staging;
   size_t ops_total = 0, consts_total = 0;
+  try {
+    tapes.resize(n);
+  } catch (const std::bad_alloc&) {
+    return fail(ctx, ZKIR_E_NOMEM, "host bookkeeping");
+  }
   for (uint32_t k = 0; k < n; k++) {
     if (!zkir::check_tape(hdrs[k], blobs[k], bytes[k], &why))
-      return fail(ctx, ZKIR_E_INVALID, "bad tape " + std::to_string(k) + ": " + why);
+      return fail(ctx, ZKIR_E_INVALID, (n > 1 ? "bad tape " + std::to_string(k) + ": " : std::string("bad tape: ")) + why);
     DevTape& t = tapes[k];
     t.hdr = hdrs[k];
-    for (uint32_t i = 0; i < hdrs[k].n_ops; i++) {
-      const uint32_t c = ((const zkir_op*)blobs[k])[i].code & 0xffu;
-      if (c == ZKIR_OP_BNOT || c == ZKIR_OP_BNOT256 || (c >= ZKIR_OP_POW && c <= ZKIR_OP_SHL)) t.full = true;
-    }
+    t.full = tape_is_full(hdrs[k], blobs[k]);
     if (t.full && (hdrs[k].flags & ZKIR_TAPE_F_STRANDS))
       return fail(ctx, ZKIR_E_INVALID, "bad tape: strand tapes are made of + - * and data movement only");
     ops_total += (size_t)hdrs[k].n_ops * sizeof(zkir_op);
@@ -383,16 +512,18 @@ int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hd
   }
   if (consts_total / 32 >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "too many constants in one upload");
   const size_t consts_off = (ops_total + 255) & ~(size_t)255;
+  const size_t descs_off = (consts_off + consts_total + 255) & ~(size_t)255;
+  const size_t total = descs_off + (size_t)n * sizeof(TapeDesc);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  std::vector<char> staging;
   try {
-    staging.resize(consts_off + consts_total);
+    staging.resize(total);
   } catch (const std::bad_alloc&) {
     return fail(ctx, ZKIR_E_NOMEM, "host staging buffer");
   }
   void* base = nullptr;
   int slab = -1;
-  int32_t rc = arena_alloc(ctx, consts_off + consts_total, &base, &slab);
+  size_t mark = 0;
+  int32_t rc = arena_alloc(ctx, total, &base, &slab, &mark);
   if (rc) return rc;
   size_t o = 0, c = consts_off;
   for (uint32_t k = 0; k < n; k++) {
@@ -401,25 +532,32 @@ int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hd
     if (cb) std::memcpy(staging.data() + c, (const char*)blobs[k] + ob, cb);
     tapes[k].ops = (char*)base + o;
     tapes[k].consts = (char*)base + c;
+    tapes[k].desc = (char*)base + descs_off + (size_t)k * sizeof(TapeDesc);
     tapes[k].slab = slab;
+    const TapeDesc d = make_desc(tapes[k], 0, 0, 0);
+    std::memcpy(staging.data() + descs_off + (size_t)k * sizeof(TapeDesc), &d, sizeof d);
     o += ob;
     c += cb;
   }
-  hipError_t e = hipSuccess;
-  if (!staging.empty()) e = hipMemcpy(base, staging.data(), staging.size(), hipMemcpyHostToDevice);
+  // synchronous copy from pageable memory: `staging` may go when it returns
+  hipError_t e = hipMemcpy(base, staging.data(), staging.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess)
     e = zkir::launch_consts_to_mont((uint32_t*)((char*)base + consts_off), (uint32_t)(consts_total / 32), nullptr);
   if (e == hipSuccess) e = hipEventRecord(ctx->upload_done, nullptr);
   if (e != hipSuccess) {
-    ctx->slabs[slab].live--;
+    arena_rollback(ctx, slab, mark, total);
     return hip_fail(ctx, e, "tape upload");
+  }
+  try {
+    for (uint32_t k = 0; k < n; k++) ctx->tapes[ctx->next_id + k] = tapes[k];
+  } catch (const std::bad_alloc&) {
+    for (uint32_t k = 0; k < n; k++) ctx->tapes.erase(ctx->next_id + k);
+    arena_rollback(ctx, slab, mark, total);
+    return fail(ctx, ZKIR_E_NOMEM, "host bookkeeping");
   }
   ctx->slabs[slab].live += (int)n - 1;  // arena_alloc counted one; every tape is released on its own
   ctx->upload_pending = true;
-  for (uint32_t k = 0; k < n; k++) {
-    out[k] = ctx->next_id++;
-    ctx->tapes[out[k]] = tapes[k];
-  }
+  for (uint32_t k = 0; k < n; k++) out[k] = ctx->next_id++;
   return ZKIR_OK;
 }
 
@@ -430,7 +568,7 @@ int32_t zkir_tape_release(zkir_ctx* ctx, zkir_tape_id id) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->launched_since_sync) {  // no launch may still be reading the tape
     HIP_TRY(ctx, hipDeviceSynchronize());
-    ctx->launched_since_sync = false;
+    note_device_idle(ctx);
   }
   ctx->slabs[it->second.slab].live--;
   ctx->tapes.erase(it);
@@ -446,7 +584,7 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(ctx, init_result(result_dev, s));
-  return run_tapes(ctx, &tape, 1, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s);
+  return run_one(ctx, it->second, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s, nullptr, 0);
 }
 
 namespace {
@@ -542,15 +680,16 @@ int32_t zkir_eval_batch(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs
 }
 
 int32_t zkir_eval_multi_dev(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs_dev,
-                            uint64_t N_per_tape, uint64_t* per_tape_unsat_dev, void* stream) {
+                            uint64_t N_per_tape, uint64_t* per_tape_unsat_dev, uint64_t* result_dev, void* stream) {
   if (!ctx || (!tapes && n_tapes) || (!per_tape_unsat_dev && n_tapes)) return ZKIR_E_INVALID;
-  if (n_tapes == 0) return ZKIR_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
+  // without a caller buffer the statistics land in the context's own words (read by the host-pointer form)
+  uint64_t* res = result_dev ? result_dev : (uint64_t*)ctx->result_buf;
+  HIP_TRY(ctx, init_result(res, s));
+  if (n_tapes == 0) return ZKIR_OK;
   HIP_TRY(ctx, hipMemsetAsync(per_tape_unsat_dev, 0, (size_t)n_tapes * sizeof(uint64_t), s));
-  HIP_TRY(ctx, init_result((uint64_t*)ctx->result_buf, s));
-  return run_tapes(ctx, tapes, n_tapes, inputs_dev, N_per_tape, nullptr, per_tape_unsat_dev,
-                   (uint64_t*)ctx->result_buf + 1, s);
+  return run_tapes(ctx, tapes, n_tapes, inputs_dev, N_per_tape, nullptr, per_tape_unsat_dev, res + 1, s);
 }
 
 int32_t zkir_eval_multi(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs,
@@ -571,7 +710,7 @@ int32_t zkir_eval_multi(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tap
   if (rc) return rc;
   if (in_bytes) HIP_TRY(ctx, hipMemcpy(ctx->io_in, inputs, in_bytes, hipMemcpyHostToDevice));
   rc = zkir_eval_multi_dev(ctx, tapes, n_tapes, (const uint32_t*)ctx->io_in, N_per_tape, (uint64_t*)ctx->io_unsat,
-                           nullptr);
+                           nullptr, nullptr);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpy(per_tape_unsat, ctx->io_unsat, (size_t)n_tapes * sizeof(uint64_t), hipMemcpyDeviceToHost));
   uint64_t res[4];
