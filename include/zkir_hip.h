@@ -344,6 +344,23 @@ int32_t zkir_eval_batch(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs
 int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa_dev, uint64_t N,
                             uint32_t* outputs_soa_dev, uint64_t* result_dev, void* stream);
 
+/* zkir_eval_batch_dev for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * arguments, same results; the work counter and the witness slots live in a fixed array of
+ * ZKIR_NOALLOC_SCRATCH_BYTES of device memory that every GPU the library runs on holds from
+ * the first zkir_ctx_create until the process ends, and the call makes no hipMalloc / hipFree
+ * (the tape and its descriptor are on the device since zkir_tape_upload).  The array has room
+ * for ZKIR_NOALLOC_SLOT_ROWS witness-slot rows of 8 KiB: a tape with more device slots than
+ * that (n_gslots of its header) is refused with ZKIR_E_LIMIT, and a launch gets only as many
+ * workgroups as rows / n_gslots, so big tapes run below the rate of zkir_eval_batch_dev.
+ * All contexts of one GPU share the array: calls that overlap on one GPU (two contexts, two
+ * processes do not count: each has its own copy) race; calls of one context are chained like
+ * every other launch of it. */
+#define ZKIR_NOALLOC_SCRATCH_BYTES (64u << 20)
+#define ZKIR_NOALLOC_SLOT_ROWS (ZKIR_NOALLOC_SCRATCH_BYTES / 8192u - 1u)
+int32_t zkir_eval_batch_dev_noalloc(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa_dev, uint64_t N,
+                                    uint32_t* outputs_soa_dev, uint64_t* result_dev, void* stream);
+
 /* Many tapes, N_per_tape vectors each: one tape per workgroup.
  *   inputs  concatenation of each tape's [n_inputs][8][N_per_tape] block
  *   per_tape_unsat [n_tapes]  unsatisfied pairs per tape

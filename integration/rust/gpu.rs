@@ -49,6 +49,12 @@ extern "C" {
     // a launch's worth of tapes in one copy (campaigns); ids come back in `out[0..n)`
     fn zkir_tape_upload_many(ctx: *mut c_void, n: u32, hdrs: *const TapeHdr, blobs: *const *const c_void,
                              bytes: *const usize, out: *mut u32) -> i32;
+    // zkir_eval_batch on device pointers and a stream; `_noalloc`: the same on the library's fixed scratch
+    // array (no hipMalloc in the call: for hosts that run under HIP graph capture)
+    fn zkir_eval_batch_dev(ctx: *mut c_void, tape: u32, inputs_soa_dev: *const u32, n: u64, outputs_soa_dev: *mut u32,
+                           result_dev: *mut u64, stream: *mut c_void) -> i32;
+    fn zkir_eval_batch_dev_noalloc(ctx: *mut c_void, tape: u32, inputs_soa_dev: *const u32, n: u64,
+                                   outputs_soa_dev: *mut u32, result_dev: *mut u64, stream: *mut c_void) -> i32;
     fn zkir_eval_multi(ctx: *mut c_void, tapes: *const u32, n_tapes: u32, inputs: *const u32, n_per_tape: u64,
                        per_tape_unsat: *mut u64) -> i32;
     fn zkir_eval_batch(ctx: *mut c_void, tape: u32, inputs_soa: *const u32, n: u64, outputs_soa: *mut u32,

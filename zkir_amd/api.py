@@ -91,6 +91,7 @@ def _load():
         "zkir_eval_batch": [c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, P(c_uint64), P(c_uint32)],
         "zkir_eval_batch_dev": [c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p],
         "zkir_eval_multi": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, P(c_uint64)],
+        "zkir_eval_batch_dev_noalloc": [c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p],
         "zkir_eval_multi_dev": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p],
         "zkir_last_faults": [c_void_p, P(c_uint64)],
         "zkir_measure_int_mul_rate": [c_void_p, c_int32, P(c_double)],
@@ -380,6 +381,10 @@ class Context:
         self._check(lib.zkir_last_faults(self._h, byref(faults)))
         return [unsat[i] for i in range(len(tids))], faults.value
 
+    def eval_batch_dev_noalloc(self, tid, inputs_ptr, n, outputs_ptr, result_ptr, stream=None):
+        """eval_batch_dev on the library's fixed scratch array: the call allocates nothing."""
+        self._check(lib.zkir_eval_batch_dev_noalloc(self._h, tid, inputs_ptr, n, outputs_ptr, result_ptr, stream))
+
     def eval_multi_dev(self, tids, inputs_ptr, n_per_tape, unsat_ptr, stream=None, result_ptr=None):
         """result_ptr: None, or 4 uint64 of device memory for {0, first unsat pair, faults, reserved}."""
         ids = (c_uint32 * len(tids))(*tids)
@@ -395,3 +400,8 @@ class Context:
         self._check(lib.zkir_measure_fr_mul_rate(self._h, byref(d)))
         return d.value
 
+
+def lib_noalloc_slot_rows():
+    """ZKIR_NOALLOC_SLOT_ROWS of include/zkir_hip.h: witness-slot rows in the fixed scratch of
+    zkir_eval_batch_dev_noalloc (64 MiB of 8 KiB rows, the first row holds the work counter)."""
+    return (64 << 20) // 8192 - 1

@@ -87,6 +87,7 @@ struct zkir_ctx {
   hipEvent_t desc_copied[2] = {nullptr, nullptr};
   bool desc_copy_recorded[2] = {false, false};
   int desc_turn = 0;
+  unsigned char* static_scratch = nullptr;  // this device's copy of the file-scope scratch array below
 };
 
 namespace {
@@ -423,6 +424,11 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
 
 }  // namespace
 
+// Scratch of zkir_eval_batch_dev_noalloc: the work counter (first 8 KiB) and witness-slot rows of 8 KiB.
+// Every GPU the library runs on holds its own copy until the process ends.  In host code the array's name
+// is only a handle for hipGetSymbolAddress; the address kernels and memsets use is zkir_ctx::static_scratch.
+static __device__ __align__(256) unsigned char scratch[ZKIR_NOALLOC_SCRATCH_BYTES];
+
 extern "C" {
 
 int32_t zkir_ctx_create(int32_t device, zkir_ctx** out) {
@@ -438,10 +444,12 @@ int32_t zkir_ctx_create(int32_t device, zkir_ctx** out) {
   if (!ctx) return ZKIR_E_NOMEM;
   ctx->device = device;
   ctx->n_cu = prop.multiProcessorCount;
+  // with `device` current: the address of this device's copy of the scratch array
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->result_buf, 4 * sizeof(uint64_t)) != hipSuccess ||
       hipMalloc(&ctx->work_counter, 256) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->upload_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->launch_done, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->launch_done, hipEventDisableTiming) != hipSuccess ||
+      hipGetSymbolAddress((void**)&ctx->static_scratch, HIP_SYMBOL(scratch)) != hipSuccess || !ctx->static_scratch) {
     if (ctx->result_buf) (void)hipFree(ctx->result_buf);
     if (ctx->work_counter) (void)hipFree(ctx->work_counter);
     if (ctx->upload_done) (void)hipEventDestroy(ctx->upload_done);
@@ -585,6 +593,20 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(ctx, init_result(result_dev, s));
   return run_one(ctx, it->second, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s, nullptr, 0);
+}
+
+int32_t zkir_eval_batch_dev_noalloc(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa_dev, uint64_t N,
+                                    uint32_t* outputs_soa_dev, uint64_t* result_dev, void* stream) {
+  if (!ctx || !result_dev) return ZKIR_E_INVALID;
+  auto it = ctx->tapes.find(tape);
+  if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
+  if (it->second.hdr.n_inputs && N && !inputs_soa_dev) return fail(ctx, ZKIR_E_INVALID, "inputs required");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(ctx, init_result(result_dev, s));
+  // the counter is cleared by run_one; slot rows need no clearing (a tape writes a slot before it reads it)
+  return run_one(ctx, it->second, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s, ctx->static_scratch,
+                 (size_t)ZKIR_NOALLOC_SCRATCH_BYTES);
 }
 
 namespace {
