@@ -366,6 +366,27 @@ class Lane:
             if op == "v_add_u32" and r > M32:
                 raise ModelError("v_add_u32 wrapped: an address computation overflowed")
             self.vwrite(a[0], r)
+        elif op in ("v_and_b32", "v_sub_u32", "v_mul_hi_u32"):
+            x, y = self.vread(a[1]), self.vread(a[2])
+            if op == "v_sub_u32" and x < y:
+                raise ModelError("v_sub_u32 went negative (%#x - %#x)" % (x, y))
+            self.vwrite(a[0], {"v_and_b32": x & y, "v_sub_u32": x - y, "v_mul_hi_u32": (x * y) >> 32}[op])
+        elif op in ("v_lshrrev_b32", "v_ashrrev_i32"):
+            sh, x = self.vread(a[1]) & 31, self.vread(a[2])
+            if op == "v_ashrrev_i32" and x >> 31:
+                x -= 1 << 32
+            self.vwrite(a[0], (x >> sh) & M32)
+        elif op == "v_lshrrev_b64":
+            lo, hi = self.vrange(a[2], 2)
+            v = (self.vread(lo) | (self.vread(hi) << 32)) >> (self.vread(a[1]) & 63)
+            lo, hi = self.vrange(a[0], 2)
+            self.vwrite(lo, v & M32)
+            self.vwrite(hi, v >> 32)
+        elif op == "v_alignbit_b32":  # low 32 bits of {hi, lo} >> shift
+            v = ((self.vread(a[1]) << 32) | self.vread(a[2])) >> (self.vread(a[3]) & 31)
+            self.vwrite(a[0], v & M32)
+        elif op == "v_lshl_or_b32":
+            self.vwrite(a[0], ((self.vread(a[1]) << (self.vread(a[2]) & 31)) | self.vread(a[3])) & M32)
         elif op == "v_mad_u64_u32":
             add = 0
             if a[4] != "0":
