@@ -6,10 +6,14 @@ write-back and constraint checks) over one batch of synthetic input vectors that
 already resident in device memory.  Workload: one generated circuit of about 1k
 quadratic constraints evaluated for 2^20 input vectors per GPU (the second
 configuration of BASELINE.json).  Vectors are independent, so with N GPUs every rank
-evaluates its own 2^20 vectors (weak scaling) and the only communication is one final
-RCCL all-reduce of {unsatisfied pairs, checks done}.
+evaluates its own 2^20 vectors (weak scaling: the headline `value`) and the only communication is one final
+RCCL all-reduce of {unsatisfied pairs, checks done}.  The same line carries, under "also", the
+fixed-size readings: configuration 2 and configuration 5 (the deep gadget, 2^16 vectors) with
+the batch split over the GPUs (strong scaling), and a sample of configuration 4 (a campaign of
+distinct circuits, circuit i on GPU i mod N, generate + lower + upload + evaluate + reduce).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 4 ...            starts its own 4 ranks (one per GPU) when no launcher did
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -66,6 +70,19 @@ def synthetic_inputs(torch, n_inputs, n, device, seed):
     return x.contiguous()
 
 
+def host_threads():
+    """Host threads this process may use: the CPUs it is allowed on, capped by OMP_NUM_THREADS when the
+    environment sets it (a GPU box shares its host: the variable holds one GPU's share of the cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    cap = os.environ.get("OMP_NUM_THREADS", "")
+    if cap.isdigit() and int(cap) > 0:
+        n = min(n, int(cap))
+    return max(1, n)
+
+
 def cpu_baseline(tape, inputs_sample, threads):
     """The scalar C interpreter of oracle/ on the host cores, on a bounded sample."""
     from oracle import c_oracle
@@ -78,6 +95,32 @@ def cpu_baseline(tape, inputs_sample, threads):
     return tape.hdr.n_constraints * n / dt, dt
 
 
+def self_launch(args):
+    """--gpus N without a launcher: start N ranks of this script as fresh child processes, one per GPU.
+    The parent never touches the GPU (it does not even import torch); rank 0's child prints the line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +128,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-vectors", type=int, default=LOG2_VECTORS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (no \"also\" entries)")
+    ap.add_argument("--campaign-circuits", type=int, default=4096,
+                    help="circuits of the configuration-4 sample under \"also\" (the whole job's, shared i mod N)")
     ap.add_argument("--no-outputs", action="store_true",
                     help="config2 only: do not ask for the outputs (witness and checks only): a measurement aid")
     ap.add_argument("--workload", default="config2", choices=["config2", "gadget"],
@@ -104,6 +150,9 @@ def main():
                          "addition-heavy variant)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -114,14 +163,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # ZKIR_BENCH_REHEARSE=1: every rank on GPU 0 and gloo instead of RCCL, to walk the N > 1 control flow on a
-    # one-GPU box (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
-    rehearse = os.environ.get("ZKIR_BENCH_REHEARSE") == "1"
+    # one-GPU box (RCCL refuses two ranks on one device); the numbers of such a run mean nothing.
+    # ZKIR_BENCH_DRYRUN=1: no GPU at all (gloo, no launches): the launcher, the barriers, the reductions and the
+    # line's schema can be exercised on a CPU-only machine; the line says "dry_run" and its numbers mean nothing.
+    dry = os.environ.get("ZKIR_BENCH_DRYRUN") == "1"
+    rehearse = os.environ.get("ZKIR_BENCH_REHEARSE") == "1" or dry
     if rehearse:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if dry:
+        device = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if world > 1:
         if rehearse:
             dist.init_process_group("gloo")
@@ -136,10 +191,66 @@ def main():
         else:
             dist.all_reduce(t, op=op)
 
+    def fence():
+        if world > 1:
+            dist.barrier()
+        if not dry:
+            torch.cuda.synchronize()
+
+    ctx = None if dry else z.Context(local_rank)
+    stream = None if dry else torch.cuda.current_stream().cuda_stream
+
+    def measure(tape, n, want_outputs, steps, warmup, seed):
+        """W untimed and K timed launches of `tape` over this rank's n vectors, bracketed by barrier + device
+        synchronisation; returns the whole job's totals and the MAX over ranks of the elapsed time."""
+        h = tape.hdr
+        tid = None if dry else ctx.upload(tape)
+        inp = synthetic_inputs(torch, h.n_inputs, n, device, seed)
+        out = torch.empty((h.n_outputs, 8, n), dtype=torch.int32, device=device) if want_outputs else None
+        out_ptr = out.data_ptr() if out is not None else None
+        res = torch.zeros(4, dtype=torch.int64, device=device)
+        totals = torch.zeros(2, dtype=torch.int64, device=device)
+
+        def launch():
+            if not dry:
+                ctx.eval_batch_dev(tid, inp.data_ptr(), n, out_ptr, res.data_ptr(), stream)
+
+        totals[0] += res[0]  # the first use of these torch kernels loads them: not inside the timed region
+        totals[1] += h.n_constraints * n
+        for _ in range(warmup):
+            launch()
+        fence()
+        totals.zero_()
+        # per-launch kernel time on the launching stream (HIP events), beside the wall clock
+        ev = [] if dry else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        fence()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            if not dry:
+                ev[k][0].record()
+            launch()
+            if not dry:
+                ev[k][1].record()
+            totals[0] += res[0]
+            totals[1] += h.n_constraints * n
+        if world > 1:
+            all_reduce(totals)  # the path's only exchange: mismatch count and checks done
+        fence()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        if world > 1:
+            all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        unsat_total, checks_total = (int(v) for v in totals.cpu())
+        kernel_ms = (elapsed * 1e3 / steps) if dry else sum(a.elapsed_time(b) for a, b in ev) / steps
+        if not dry:
+            ctx.release(tid)
+        return {"unsat": unsat_total, "checks": checks_total, "elapsed": elapsed, "kernel_ms": kernel_ms, "inputs": inp}
+
     gadget = args.workload == "gadget"
     if gadget and args.log2_vectors == LOG2_VECTORS:
         args.log2_vectors = 16
-    n = 1 << args.log2_vectors
+    n = 1 << (10 if dry else args.log2_vectors)
     if args.strong:
         if n % world:
             raise SystemExit("--strong needs a batch the ranks divide evenly")
@@ -149,66 +260,86 @@ def main():
     strands = 4 if args.strands == "auto" else int(args.strands)
     tape = gadget_tape(z, args.gadget_rounds, strands) if gadget else workload_tape(z, args.signal_window, args.linear_terms)
     h = tape.hdr
-    ctx = z.Context(local_rank)
-    tid = ctx.upload(tape)
-    inp = synthetic_inputs(torch, h.n_inputs, n, device, 1000 + rank)  # every rank its own vectors
     want_outputs = not gadget and not args.no_outputs
-    out = torch.empty((h.n_outputs, 8, n), dtype=torch.int32, device=device) if want_outputs else None
-    out_ptr = out.data_ptr() if out is not None else None
-    res = torch.zeros(4, dtype=torch.int64, device=device)
-    totals = torch.zeros(2, dtype=torch.int64, device=device)
-    stream = torch.cuda.current_stream().cuda_stream
+    m = measure(tape, n, want_outputs, args.steps, args.warmup, 1000 + rank)  # every rank its own vectors
+    elapsed, kernel_ms, inp = m["elapsed"], m["kernel_ms"], m["inputs"]
 
-    def step():
-        ctx.eval_batch_dev(tid, inp.data_ptr(), n, out_ptr, res.data_ptr(), stream)
-        totals[0] += res[0]
-        totals[1] += h.n_constraints * n
+    # ---- the fixed-size readings and the campaign sample ("also") -----------------------------------------
+    also = []
+    if not args.no_extras and not gadget and not args.strong and args.signal_window == 0 and args.linear_terms == 1 \
+            and not args.no_outputs and args.log2_vectors == LOG2_VECTORS:
+        mulhi_peak_x = 1.0 if dry else ctx.int_mul_rate(0)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def entry(name, tp, mm, n_rank, steps, scaling):
+            hh = tp.hdr
+            fr = (hh.n_mul_ops + hh.n_constraints) * n_rank
+            return {"workload": name, "scaling": scaling, "value": mm["checks"] / mm["elapsed"], "unit": "checks/s",
+                    "ms_per_step": 1e3 * mm["elapsed"] / steps, "kernel_ms": mm["kernel_ms"], "vectors_per_gpu": n_rank,
+                    "n_constraints": hh.n_constraints, "strand_tape": bool(hh.flags & 1),
+                    "fr_mul_per_s": fr * world / (mm["elapsed"] / steps),
+                    "mulhi_frac": 128.0 * fr / (mm["kernel_ms"] * 1e-3) / mulhi_peak_x}
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    totals.zero_()
-    # per-launch kernel time on the launching stream (HIP events), beside the wall clock
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        ctx.eval_batch_dev(tid, inp.data_ptr(), n, out_ptr, res.data_ptr(), stream)
-        ev[k][1].record()
-        totals[0] += res[0]
-        totals[1] += h.n_constraints * n
-    if world > 1:
-        all_reduce(totals)  # the path's only exchange: mismatch count and checks done
-    fence()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    unsat_total, checks_total = (int(v) for v in totals.cpu())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+        if world > 1 and (1 << LOG2_VECTORS) % world == 0:
+            n2 = (1 << (10 if dry else LOG2_VECTORS)) // world
+            mm = measure(tape, n2, True, args.steps, min(args.warmup, 2), 2000 + rank)
+            also.append(entry("configuration 2 as a fixed batch: the same circuit x 2^%d vectors split over the GPUs"
+                              % LOG2_VECTORS, tape, mm, n2, args.steps, "strong"))
+        if (1 << 16) % world == 0:
+            g_rounds = 20 if dry else args.gadget_rounds
+            gt = gadget_tape(z, g_rounds, 4)
+            n5 = (1 << (8 if dry else 16)) // world
+            k5 = max(1, min(args.steps, 5))
+            mm = measure(gt, n5, False, k5, 1, 3000 + rank)
+            assert mm["unsat"] == 0
+            also.append(entry("configuration 5: Poseidon-style gadget chain (width 4, %d rounds, %d constraints) x 2^16 "
+                              "vectors split over the GPUs; witness + checks" % (g_rounds, gt.hdr.n_constraints),
+                              gt, mm, n5, k5, "strong"))
+        if args.campaign_circuits > 0:
+            from zkir_amd import campaign
+            n_circ, n_vec = (64 if dry else args.campaign_circuits), (16 if dry else 1024)
+            ids = campaign.shard(n_circ, rank, world)
+            workers = max(1, min(8, host_threads() // max(1, world if rehearse else 1)))
+            if dry:
+                def evaluator(tapes, n_vectors, circuit_ids):  # no GPU: the lowering and the exchange still run
+                    return [0] * len(tapes), 0
+            else:
+                evaluator = campaign.GpuEvaluator(local_rank, input_seed=7 + rank)
+            fence()
+            t0 = time.perf_counter()
+            res_c = campaign.run_local(ids, 7, n_vec, evaluator, group=2048,
+                                       lowered=campaign.lower_parallel(ids, 7, workers=workers))
+            tot = campaign.reduce_results(res_c, dist if world > 1 else None, device if not rehearse else None)
+            fence()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            if world > 1:
+                all_reduce(dt, op=dist.ReduceOp.MAX)
+            dt = float(dt.item())
+            if not dry:
+                evaluator.close()
+            also.append({"workload": "configuration 4 (sample): campaign of %d distinct circuits (64 to 4 096 constraints) x %d "
+                                     "vectors each, circuit i on GPU i mod N; generate + lower + upload + evaluate + reduce"
+                                     % (n_circ, n_vec),
+                         "scaling": "strong", "value": tot["checks"] / dt, "unit": "checks/s", "seconds": dt,
+                         "circuits_per_s": tot["circuits"] / dt, "circuits": tot["circuits"], "rejected": tot["rejected"],
+                         "unsat": tot["unsat"], "faults": tot["faults"], "n_divergent": tot["n_divergent"],
+                         "host_threads_per_rank": workers})
 
     if rank == 0:
+        unsat_total, checks_total = m["unsat"], m["checks"]
         if world == 1:
             assert checks_total == h.n_constraints * n * args.steps
         assert unsat_total == 0, "synthetic witnesses must satisfy every constraint"
         value = checks_total / elapsed
         fr_muls = (h.n_mul_ops + h.n_constraints) * n  # per launch: one Montgomery product per Mul op and per check
-        mulhi_peak = ctx.int_mul_rate(0)
-        fr_peak = ctx.fr_mul_rate()
+        mulhi_peak = 1.0 if dry else ctx.int_mul_rate(0)
+        fr_peak = 1.0 if dry else ctx.fr_mul_rate()
         achieved = 128.0 * fr_muls / (kernel_ms * 1e-3)
         alg_bytes = (32 * (h.n_inputs + (h.n_outputs if want_outputs else 0)) + 4) * n
         # HBM bytes per launch from the counter passes committed under profiles/ (only for the
         # exact workload they were taken on; counters cannot be read from inside this process)
         traffic = None
         if (want_outputs and args.signal_window == 0 and args.log2_vectors == LOG2_VECTORS and not args.strong
-                and not any(k.startswith("ZKIR_") for k in os.environ)):
+                and not gadget and not any(k.startswith("ZKIR_") for k in os.environ)):
             try:
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                     key = "config2_seed%d_2^%d_window4_terms%d" % (WORKLOAD_SEED, LOG2_VECTORS, args.linear_terms)
@@ -265,19 +396,25 @@ def main():
                 "traffic_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            threads = min(16, os.cpu_count() or 1)
-            sample = min(n, (64 if gadget else 8192) * threads)  # about 20 core-seconds of work in all
+        if also:
+            line["also"] = also
+        if dry:
+            line["dry_run"] = True
+        if world == 1 and not args.no_cpu_baseline and not dry:
+            threads = host_threads()
+            sample = min(n, (64 if gadget else 8192) * min(threads, 32))  # 10 to 30 s of CPU work in all
             inp_s = np.ascontiguousarray(inp[:, :, :sample].cpu().numpy().view(np.uint32))
             cps, dt = cpu_baseline(tape, inp_s, threads)
             one = max(1, sample // 4)
             cps1, dt1 = cpu_baseline(tape, np.ascontiguousarray(inp_s[:, :, :one]), 1)
             line["cpu_baseline"] = {"value": cps, "unit": "checks/s", "cores": threads, "kind": "port",
-                                    "sample": "first %d vectors of the same batch, %d threads, %.1f s" % (sample, threads, dt),
+                                    "host_cpus": os.cpu_count(),
+                                    "sample": "first %d vectors of the same batch, %d threads (every core this process may "
+                                              "use; the machine shows %s), %.1f s" % (sample, threads, os.cpu_count(), dt),
                                     "one_core": {"value": cps1, "sample": "first %d vectors, 1 thread, %.1f s" % (one, dt1)}}
         print(json.dumps(line), flush=True)
-    ctx.release(tid)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

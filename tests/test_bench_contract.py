@@ -46,3 +46,28 @@ def test_traffic_file_matches_profiles():
         assert os.path.exists(os.path.join(ROOT, ent["source"])), ent["source"]
         want = ent["fetch_size_kb_raw"] * 2048 + ent["write_size_kb"] * 1024
         assert abs(ent["bytes_per_launch"] - want) / want < 1e-6
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself and rank 0 prints one line.  Here
+    without a GPU (ZKIR_BENCH_DRYRUN=1: gloo, no launches), so only the launcher, the barriers, the reductions,
+    the campaign sample's sharding and the line's shape are exercised."""
+    import subprocess
+    import sys
+    env = dict(os.environ, ZKIR_BENCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    cfg = d["config"]
+    assert abs(d["value"] - cfg["n_constraints"] * cfg["vectors_per_gpu"] * 2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    kinds = [e["workload"].split(":")[0].split(" as ")[0] for e in d["also"]]
+    assert kinds == ["configuration 2", "configuration 5", "configuration 4 (sample)"]
+    assert all(e["scaling"] == "strong" and e["value"] > 0 for e in d["also"])
+    camp = d["also"][2]
+    assert camp["circuits"] == 64 and camp["unsat"] == 0  # both ranks' shares were counted once each

@@ -125,3 +125,75 @@ def test_verdict_comparison(tmp_path):
     assert X.compare_case(d) == {"verdict": ["DoubleAssign", "Ok"]}
     assert X.classify_circom_log("error[T3001]: Non quadratic constraints are not allowed!") == "NonQuadratic"
     assert X.classify_circom_log("error[P1000]: something new") == "Other"
+
+
+# ---- byte strings assembled by hand from iden3's published layouts (not through this module's writers) ----
+P_LE = bytes.fromhex("010000f093f5e1439170b97948e833285d588181b64550b829a031e1724e6430")  # p, 32 bytes little-endian
+
+
+def _fe(v):
+    return bytes([(v >> (8 * i)) & 0xFF for i in range(32)])
+
+
+def test_hand_assembled_wtns_bytes():
+    """wtns v2: "wtns", version, section count; section 1 = {n8, prime, witness count}, section 2 = the values."""
+    assert int.from_bytes(P_LE, "little") == F.P
+    vals = [1, 33, F.P - 2, 1 << 200]
+    hdr = bytes([32, 0, 0, 0]) + P_LE + bytes([4, 0, 0, 0])
+    body = b"".join(_fe(v) for v in vals)
+    data = (b"wtns" + bytes([2, 0, 0, 0]) + bytes([2, 0, 0, 0])
+            + bytes([1, 0, 0, 0]) + bytes([40, 0, 0, 0, 0, 0, 0, 0]) + hdr
+            + bytes([2, 0, 0, 0]) + bytes([128, 0, 0, 0, 0, 0, 0, 0]) + body)
+    assert len(data) == 12 + 12 + 40 + 12 + 128
+    assert X.read_wtns(data) == (F.P, vals)
+    assert X.write_wtns(vals) == data  # the module's writer produces the same bytes
+    # sections in the other order (the container allows any)
+    swapped = (b"wtns" + bytes([2, 0, 0, 0, 2, 0, 0, 0])
+               + bytes([2, 0, 0, 0, 128, 0, 0, 0, 0, 0, 0, 0]) + body
+               + bytes([1, 0, 0, 0, 40, 0, 0, 0, 0, 0, 0, 0]) + hdr)
+    assert X.read_wtns(swapped) == (F.P, vals)
+
+
+def test_hand_assembled_r1cs_bytes():
+    """r1cs v1: header section {n8, prime, nWires, nPubOut, nPubIn, nPrvIn, nLabels (u64), mConstraints},
+    constraint section {per linear combination: term count, (wire u32, coefficient n8 bytes)...}, wire-to-label
+    section {u64 per wire}; here one constraint (3*w2 + 1) * w3 == w1 - w2 over wires {one, out, a, b}, with the
+    sections in the order circom writes them."""
+    u32 = lambda v: bytes([(v >> (8 * i)) & 0xFF for i in range(4)])  # noqa: E731
+    u64 = lambda v: bytes([(v >> (8 * i)) & 0xFF for i in range(8)])  # noqa: E731
+    hdr = u32(32) + P_LE + u32(4) + u32(1) + u32(0) + u32(2) + u64(4) + u32(1)
+    lc_a = u32(2) + u32(0) + _fe(1) + u32(2) + _fe(3)
+    lc_b = u32(1) + u32(3) + _fe(1)
+    lc_c = u32(2) + u32(1) + _fe(1) + u32(2) + _fe(F.P - 1)
+    cons = lc_a + lc_b + lc_c
+    w2l = u64(0) + u64(1) + u64(2) + u64(3)
+    data = (b"r1cs" + u32(1) + u32(3)
+            + u32(1) + u64(len(hdr)) + hdr + u32(2) + u64(len(cons)) + cons + u32(3) + u64(len(w2l)) + w2l)
+    r = X.read_r1cs(data)
+    assert (r["prime"], r["n_wires"], r["n_pub_out"], r["n_pub_in"], r["n_prv_in"], r["n_labels"]) == (F.P, 4, 1, 0, 2, 4)
+    assert r["constraints"] == [({0: 1, 2: 3}, {3: 1}, {1: 1, 2: F.P - 1})] and r["wire2label"] == [0, 1, 2, 3]
+    assert X.write_r1cs(4, 1, 0, 2, r["constraints"]) == data
+    a, b = 12345, F.P - 7
+    good = [1, ((3 * a + 1) * b + a) % F.P, a, b]
+    assert X.failed_constraints(r, good) == []
+    assert X.failed_constraints(r, good[:1] + [good[1] + 1] + good[2:]) == [0]
+    # constraint section before the header (readers must not assume an order)
+    moved = (b"r1cs" + u32(1) + u32(3)
+             + u32(2) + u64(len(cons)) + cons + u32(3) + u64(len(w2l)) + w2l + u32(1) + u64(len(hdr)) + hdr)
+    assert X.read_r1cs(moved) == r
+
+
+def test_oracle_header_symbol_lives_in_the_checker_library_only():
+    import ctypes
+    import re
+
+    from oracle import c_oracle
+    from zkir_amd import api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "zkir_oracle.h")).read(), flags=re.S)
+    names = set(re.findall(r"\b(zkir_[a-z0-9_]+)\s*\(", hdr))
+    assert names == {"zkir_eval_cpu"}
+    c_oracle.build()
+    checker = ctypes.CDLL(os.path.join(root, "oracle", "_build", "libzkir_oracle.so"))
+    product = ctypes.CDLL(api.LIB_PATH)
+    assert hasattr(checker, "zkir_eval_cpu") and not hasattr(product, "zkir_eval_cpu")

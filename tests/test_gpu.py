@@ -681,3 +681,30 @@ def test_tape_with_more_device_slots_than_the_generated_stream_addresses(ctx):
     out, unsat, _, _ = check_against_c_oracle(ctx, tape, vecs)
     assert unsat == 0 and z.unpack_outputs(out[:, :, 5:6])[0] == [F.add(F.mul(vecs[5][0], vecs[5][1]), vecs[5][0]), vecs[5][0]]
     torch.cuda.empty_cache()
+
+
+def test_circuits_with_if_statements_against_both_checkers(ctx):
+    """The generator's If statements with conditions lower can decide (enable_if = 2): the tape of the taken
+    branches on the GPU against the C checker, and against the direct interpretation of the AST."""
+    n_ok = n_if = 0
+    for seed in range(1, 60):
+        c = z.Generator(seed, ext_config(min_instructions=120, max_instructions=160, forced_inputs=4, inputs_readable=1,
+                                         safe_array_index=1, arithmetic_only=seed % 2, quadratic_aware=1, no_loops=seed % 3 == 0,
+                                         enable_if=2)).generate()
+        txt = c.text()
+        o = z.default_lower_options()
+        o.max_iterations = 300
+        try:
+            tape = z.Lowerer(c, o).lower()
+        except z.LowerRejected:
+            continue
+        n_ok += 1
+        n_if += "(if " in txt
+        vecs = random_vectors(random.Random(seed), tape.hdr.n_inputs, 64)
+        out, unsat, first, faults = check_against_c_oracle(ctx, tape, vecs)
+        got = z.unpack_outputs(out)
+        for t in (0, 63):
+            it = R.Interpreter(R.parse_text(txt), vecs[t], max_iterations=300).run()
+            assert got[t] == it.outputs and it.unsat() == []
+        assert unsat == 0
+    assert n_ok >= 10 and n_if >= 5
