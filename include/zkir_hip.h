@@ -332,7 +332,7 @@ int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hd
  *   first_unsat  nullable; [2] = {vector, constraint} of the unsatisfied pair
  *                with the smallest vector index (then smallest constraint),
  *                0xffffffff each when every constraint holds
- * N < 2^32; a strand tape takes N < 2^27 per launch and fewer than 2^19 device slots per
+ * N < 2^32; a strand tape takes N < 2^27 per launch and fewer than 466 033 device slots per
  * strand (ZKIR_E_LIMIT beyond). */
 int32_t zkir_eval_batch(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa, uint64_t N,
                         uint32_t* outputs_soa, uint64_t* unsat_count, uint32_t* first_unsat);
@@ -350,14 +350,14 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
  * ZKIR_NOALLOC_SCRATCH_BYTES of device memory that every GPU the library runs on holds from
  * the first zkir_ctx_create until the process ends, and the call makes no hipMalloc / hipFree
  * (the tape and its descriptor are on the device since zkir_tape_upload).  The array has room
- * for ZKIR_NOALLOC_SLOT_ROWS witness-slot rows of 8 KiB: a tape with more device slots than
+ * for ZKIR_NOALLOC_SLOT_ROWS witness-slot rows of 9 KiB: a tape with more device slots than
  * that (n_gslots of its header) is refused with ZKIR_E_LIMIT, and a launch gets only as many
  * workgroups as rows / n_gslots, so big tapes run below the rate of zkir_eval_batch_dev.
  * All contexts of one GPU share the array: calls that overlap on one GPU (two contexts, two
  * processes do not count: each has its own copy) race; calls of one context are chained like
  * every other launch of it. */
 #define ZKIR_NOALLOC_SCRATCH_BYTES (64u << 20)
-#define ZKIR_NOALLOC_SLOT_ROWS (ZKIR_NOALLOC_SCRATCH_BYTES / 8192u - 1u)
+#define ZKIR_NOALLOC_SLOT_ROWS (ZKIR_NOALLOC_SCRATCH_BYTES / 9216u - 1u)
 int32_t zkir_eval_batch_dev_noalloc(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa_dev, uint64_t N,
                                     uint32_t* outputs_soa_dev, uint64_t* result_dev, void* stream);
 

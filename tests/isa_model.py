@@ -96,6 +96,7 @@ class Lane:
         self.stores_waited = True  # no store (LDS or device memory) issued since the last full wait
         self.steps = 0
         self.counts = {}
+        self.wrap_ok = set()  # destination registers whose v_add_u32 may wrap (signed limb arithmetic), by name
 
     # ---- register access ---------------------------------------------------
     def _check_ready(self, name):
@@ -346,14 +347,14 @@ class Lane:
             if "vm" in kinds and "lgkm" in kinds:
                 self.stores_waited = True
         # ---- scalar memory
-        elif op in ("s_buffer_load_dwordx4", "s_buffer_load_dwordx8"):
-            n = 4 if op.endswith("x4") else 8
+        elif op in ("s_buffer_load_dword", "s_buffer_load_dwordx4", "s_buffer_load_dwordx8"):
+            n = 4 if op.endswith("x4") else 8 if op.endswith("x8") else 1
             base, records = self.descriptor(a[1])
             off = self.sread(a[2])
             if off % 4 or off + 4 * n > records:
                 raise ModelError("scalar buffer load at offset %d (+%d bytes) beyond %d" % (off, 4 * n, records))
             words = self.mem.load(base + off, n)
-            for r, w in zip(self.srange(a[0], n), words):
+            for r, w in zip(self.srange(a[0], n) if n > 1 else [a[0]], words):
                 self.swrite(r, w)
                 self.pending[r] = "lgkm"
         # ---- vector ALU
@@ -363,7 +364,7 @@ class Lane:
             x, y = self.vread(a[1]), self.vread(a[2])
             r = {"v_add_u32": x + y, "v_xor_b32": x ^ y, "v_or_b32": x | y, "v_min_u32": min(x, y),
                  "v_mul_lo_u32": x * y}[op]
-            if op == "v_add_u32" and r > M32:
+            if op == "v_add_u32" and r > M32 and a[0] not in self.wrap_ok:
                 raise ModelError("v_add_u32 wrapped: an address computation overflowed")
             self.vwrite(a[0], r)
         elif op in ("v_and_b32", "v_sub_u32", "v_mul_hi_u32"):
@@ -371,6 +372,16 @@ class Lane:
             if op == "v_sub_u32" and x < y:
                 raise ModelError("v_sub_u32 went negative (%#x - %#x)" % (x, y))
             self.vwrite(a[0], {"v_and_b32": x & y, "v_sub_u32": x - y, "v_mul_hi_u32": (x * y) >> 32}[op])
+        elif op == "v_subrev_u32":  # src1 - src0, wrapping: signed limb arithmetic
+            self.vwrite(a[0], (self.vread(a[2]) - self.vread(a[1])) & M32)
+        elif op == "v_mad_u32_u24":
+            x, y = self.vread(a[1]), self.vread(a[2])
+            if x >> 24 or y >> 24:
+                raise ModelError("v_mad_u32_u24 operand beyond 24 bits")
+            r = x * y + self.vread(a[3])
+            if r > M32:
+                raise ModelError("v_mad_u32_u24 wrapped")
+            self.vwrite(a[0], r)
         elif op in ("v_lshrrev_b32", "v_ashrrev_i32"):
             sh, x = self.vread(a[1]) & 31, self.vread(a[2])
             if op == "v_ashrrev_i32" and x >> 31:
@@ -416,12 +427,13 @@ class Lane:
         elif op == "v_cmp_ne_u32":
             self.carry_write(a[0], int(self.vread(a[1]) != self.vread(a[2])))
         # ---- LDS
-        elif op in ("ds_read_b128", "ds_write_b128"):
-            rd = op == "ds_read_b128"
+        elif op in ("ds_read_b128", "ds_write_b128", "ds_read_b32", "ds_write_b32"):
+            rd = op.startswith("ds_read")
+            nb = 16 if op.endswith("b128") else 4
             addr = self.vread(a[1] if rd else a[0]) + inst_off
-            if addr % 16 or addr + 16 > self.lds_bytes:
-                raise ModelError("LDS access at %d (+16) outside the %d-byte allocation" % (addr, self.lds_bytes))
-            regs = self.vrange(a[0] if rd else a[1], 4)
+            if addr % nb or addr + nb > self.lds_bytes:
+                raise ModelError("LDS access at %d (+%d) outside the %d-byte allocation" % (addr, nb, self.lds_bytes))
+            regs = self.vrange(a[0] if rd else a[1], nb // 4)
             for k, r in enumerate(regs):
                 if rd:
                     key = addr + 4 * k

@@ -31,14 +31,16 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(autouse=True, params=["generated-stream", "compiled"])
+@pytest.fixture(autouse=True, params=["generated-stream", "stream32", "compiled"])
 def interpreter_kernel(request):
-    """Every test runs twice: + - * tapes through the generated instruction stream (the
-    default) and through the compiled kernel (ZKIR_INTERP=compiled); tapes with other
-    operators take the compiled every-operator kernel either way."""
+    """Every test runs three times: + - * tapes through the generated instruction stream on 9 x 29-bit limbs (the
+    default), through the generated stream on 8 x 32-bit limbs (ZKIR_INTERP=lean32) and through the compiled
+    kernel (ZKIR_INTERP=compiled); tapes with other operators take the compiled every-operator kernel every time."""
     old = os.environ.get("ZKIR_INTERP")
     if request.param == "compiled":
         os.environ["ZKIR_INTERP"] = "compiled"
+    elif request.param == "stream32":
+        os.environ["ZKIR_INTERP"] = "lean32"
     else:
         os.environ.pop("ZKIR_INTERP", None)
     yield request.param
@@ -672,7 +674,7 @@ def test_tape_with_more_device_slots_than_the_generated_stream_addresses(ctx):
     """8 KiB x n_gslots no longer fits the 32-bit offsets of the generated stream: the launch takes the
     compiled kernel (64-bit addresses) and the far slots hold what was put there."""
     torch = pytest.importorskip("torch")
-    far = (1 << 19) + 2  # slot rows of 8 KiB: the last one sits past 4 GiB in the workgroup's region
+    far = (1 << 19) + 2  # slot rows of 8 or 9 KiB: the last one sits past 4 GiB in the workgroup's region
     ops = [(F.OP_INPUT, G(far), I(0), NONE), (F.OP_INPUT, G(1), I(1), NONE), (F.OP_MUL, G(far - 1), G(far), G(1)),
            (F.OP_ADD, G(2), G(far - 1), G(far)), (F.OP_OUTPUT, 0, G(2), NONE), (F.OP_OUTPUT, 1, G(far), NONE),
            (F.OP_CHECK, G(far - 1), G(1), G(far))]
@@ -708,3 +710,58 @@ def test_circuits_with_if_statements_against_both_checkers(ctx):
             assert got[t] == it.outputs and it.unsat() == []
         assert unsat == 0
     assert n_ok >= 10 and n_if >= 5
+
+
+def test_campaign_sized_launch_with_planted_failures_and_faults(ctx, interpreter_kernel):
+    """2 304 distinct campaign circuits x 1 024 vectors in ONE device-pointer launch (a campaign's launch size), two
+    every-operator tapes with a zero divisor among them: per-tape counts on the right tapes, the fault count in the
+    caller's result words, sampled tapes against the C checker."""
+    torch = pytest.importorskip("torch")
+    if interpreter_kernel != "generated-stream":
+        pytest.skip("one pass at this size is enough; the 384-tape test runs every kernel")
+    from zkir_amd import campaign
+    n_circ, n_vec = 2304, 1024
+    tapes = [t for _, cls, t in campaign.lower_parallel(range(n_circ), 4242, workers=8) if cls == 0]
+    assert len(tapes) == n_circ
+    planted = [3, 777, 1500, 2303]
+    for k in planted:  # turn the first product into a sum: the circuit's first constraint fails
+        ops = tapes[k].ops()
+        j = next(i for i, op in enumerate(ops) if op[0] == F.OP_MUL)
+        ops[j] = (F.OP_ADD,) + ops[j][1:]
+        tapes[k] = z.Tape.from_parts(tapes[k].hdr, b"".join(struct.pack("<4I", *op) for op in ops) + tapes[k].blob()[16 * len(ops):])
+    zero_div = hand_tape([(F.OP_INPUT, G(0), I(0), NONE), (F.OP_REM, G(1), G(0), K(0)), (F.OP_OUTPUT, 0, G(1), NONE)], [0], 1, 1, 2, 0)
+    fault_at = [n_circ, n_circ + 1]  # appended: a launch that holds them takes the every-operator kernel for all its tapes
+    tapes += [zero_div, zero_div]
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(9)
+    words = sum(t.hdr.n_inputs for t in tapes) * 8 * n_vec
+    inp = torch.randint(0, 1 << 32, (words,), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+    inp.view(-1, 8, n_vec)[:, 7, :] &= 0x0FFFFFFF
+    offs, off = [], 0
+    for t in tapes:
+        offs.append(off)
+        off += t.hdr.n_inputs * 8 * n_vec
+    tids = ctx.upload_many(tapes)
+    unsat = torch.zeros(len(tapes), dtype=torch.int64, device=dev)
+    res = torch.zeros(4, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    # the + - * tapes alone (the generated stream), then all of them (the compiled every-operator kernel)
+    ctx.eval_multi_dev(tids[:n_circ], inp.data_ptr(), n_vec, unsat.data_ptr(), stream, res.data_ptr())
+    torch.cuda.synchronize()
+    got = [int(v) for v in unsat.cpu()][:n_circ]
+    assert int(res.cpu().numpy().view(np.uint64)[2]) == 0
+    ctx.eval_multi_dev(tids, inp.data_ptr(), n_vec, unsat.data_ptr(), stream, res.data_ptr())
+    torch.cuda.synchronize()
+    assert [int(v) for v in unsat.cpu()] == got + [0, 0]
+    assert int(res.cpu().numpy().view(np.uint64)[2]) == len(fault_at) * n_vec
+    for k in planted + [0, 1, 1151, 2302]:
+        t = tapes[k]
+        blk = inp[offs[k]:offs[k] + t.hdr.n_inputs * 8 * n_vec].view(t.hdr.n_inputs, 8, n_vec)
+        blk = np.ascontiguousarray(blk.cpu().numpy().view(np.uint32))
+        _, u_c, _, _ = C.eval_cpu(bytes(t.hdr), t.blob(), blk, n_vec, t.hdr.n_outputs, want_outputs=False, threads=8)
+        assert got[k] == u_c, k
+    # (a changed product need not reach a constraint in every circuit: the checker's count above is the reference)
+    assert sum(1 for k in planted if got[k] > 0) >= 2 and all(g == 0 for k, g in enumerate(got) if k not in planted)
+    for t in tids:
+        ctx.release(t)

@@ -403,5 +403,5 @@ class Context:
 
 def lib_noalloc_slot_rows():
     """ZKIR_NOALLOC_SLOT_ROWS of include/zkir_hip.h: witness-slot rows in the fixed scratch of
-    zkir_eval_batch_dev_noalloc (64 MiB of 8 KiB rows, the first row holds the work counter)."""
-    return (64 << 20) // 8192 - 1
+    zkir_eval_batch_dev_noalloc (64 MiB of 9 KiB rows, the first row holds the work counter)."""
+    return (64 << 20) // 9216 - 1

@@ -8,7 +8,7 @@
 
 namespace zkir {
 
-// Device-side description of one uploaded tape (96 bytes, read with scalar loads).
+// Device-side description of one uploaded tape (104 bytes, read with scalar loads).
 struct TapeDesc {
   const zkir_op* ops;      // n_ops entries
   const uint32_t* consts;  // n_consts x 8 limbs, Montgomery form
@@ -24,7 +24,8 @@ struct TapeDesc {
   uint32_t reserved;
   uint32_t strand_begin[ZKIR_STRANDS];  // strand tapes: first op of each strand
   uint32_t strand_ops[ZKIR_STRANDS];    // strand tapes: ops of each strand
+  const uint32_t* consts29;             // n_consts x 12 words: 9 limbs of 29 bits, Montgomery form with R = 2^261
 };
-static_assert(sizeof(TapeDesc) == 96, "TapeDesc is read as 96 bytes");
+static_assert(sizeof(TapeDesc) == 104, "TapeDesc layout");
 
 }  // namespace zkir

@@ -413,6 +413,133 @@ zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, ui
   }
 }
 
+// ---- the same interpreter on 9 limbs of 29 bits --------------------------------
+// The stream of tools/gen_interp29_asm.py: values are 9 limbs of 29 bits in Montgomery form with R = 2^261, so a
+// product is 162 multiply-adds into 64-bit column sums with no carry-writing add (on gfx950 those cost as much
+// as a multiply); sums and differences are limb-wise and reduced through a table of the first 32 multiples of p
+// that the workgroup keeps at the start of its LDS.  Same work-item loop, same results.
+// Slot layout: slot s, wave w at s*9216 + w*2304; plane 0 (limbs 0..3) lane*16, plane 1 (limbs 4..7) 1024 + lane*16,
+// plane 2 (limb 8) 2048 + lane*4.  Constants come from the tape's second pool (12 words each, this form).
+// Limits the host checks before choosing this kernel: 32 * n_vectors < 2^32 and 9216 * gslots_per_block < 2^32.
+#include "interp29_core_asm.inc"
+
+constexpr uint32_t kSlot29 = 9216, kWave29 = 2304, kTable29 = 2048;
+__constant__ uint32_t zkir_p29[9] = {ZKIR_FR29_P_LIMBS};
+
+__global__ void __launch_bounds__(kBlock, 2)
+zkir_interp_lean29_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_t passes_per_tape,
+                          uint64_t n_vectors, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ outputs,
+                          uint4* __restrict__ gslot_pool, uint32_t gslots_per_block,
+                          uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats,
+                          uint32_t* __restrict__ work_counter, uint32_t victim_row, uint32_t strands, uint32_t lslots) {
+  __shared__ uint32_t next_item;
+  const uint64_t gslots = (uint64_t)(uintptr_t)((const char*)gslot_pool + (size_t)blockIdx.x * gslots_per_block * kSlot29);
+  const uint32_t gslot_bytes = gslots_per_block * kSlot29;
+  // LDS: the table of multiples of p, then the victim row (if any), the window slots, the exchange slots
+  const uint32_t lds_tab = (uint32_t)(uintptr_t)zkir_lds_slots;
+  const uint32_t lds_base = lds_tab + kTable29 + (victim_row ? kSlot29 : 0u);
+  const uint32_t xbase = lds_base + lslots * kSlot29;
+  const uint32_t evict_below = victim_row ? 0x20000000u : 0u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const uint32_t v_lo = wave * kWave29 + lane * 16u, v_lo4 = wave * kWave29 + 2048u + lane * 4u;
+  const uint32_t v_x = lane * 16u, v_x4 = 2048u + lane * 4u;
+  const uint32_t n4 = (uint32_t)n_vectors * 4u;
+  if (threadIdx.x < 32) {  // entry q: the limbs of q*p, 12 words (9 used)
+    uint32_t* row = (uint32_t*)zkir_lds_slots + threadIdx.x * 12;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      const uint64_t t = (uint64_t)zkir_p29[j] * threadIdx.x + carry;
+      row[j] = j < 8 ? (uint32_t)(t & 0x1fffffffu) : (uint32_t)t;
+      carry = t >> 29;
+    }
+    row[9] = row[10] = row[11] = 0;
+  }
+  __syncthreads();
+
+  const uint64_t total = (uint64_t)n_tapes * passes_per_tape;
+  for (;;) {
+    if (threadIdx.x == 0) next_item = atomicAdd(work_counter, 1u);
+    __syncthreads();
+    const uint64_t w = next_item;
+    __syncthreads();
+    if (w >= total) break;
+    const uint32_t tape_i = (uint32_t)(w / passes_per_tape);
+    const uint32_t pass = (uint32_t)(w % passes_per_tape);
+    uniform_desc_t tdp = (uniform_desc_t)tapes + tape_i;
+    const TapeDesc td = *tdp;
+    const uint64_t vec = strands ? (uint64_t)pass * 64u + lane : (uint64_t)pass * kBlock + threadIdx.x;
+    const bool live = vec < n_vectors;
+    const uint32_t v_vec4 = live ? (uint32_t)vec * 4u : 0u;  // idle lanes recompute vector 0 and report nothing
+    const uint64_t live_mask = __ballot(live);
+    const uint32_t first_op = strands ? tdp->strand_begin[wave] : 0u;
+    const uint32_t n_ops = strands ? tdp->strand_ops[wave] : td.n_ops;
+    const uint64_t ops = (uint64_t)(uintptr_t)(td.ops + first_op), consts = (uint64_t)(uintptr_t)td.consts29;
+    const uint64_t in_base = (uint64_t)(uintptr_t)(inputs + td.in_word_off);
+    const uint64_t out_base = outputs ? (uint64_t)(uintptr_t)(outputs + td.out_word_off) : 0;  // 0: not wanted
+
+    uint64_t wave_unsat;
+    uint32_t first_bad;
+    asm volatile(ZKIR_INTERP29_CORE_ASM
+                 : [unsat] "=s"(wave_unsat), [first] "=v"(first_bad)
+                 : [ops] "s"(ops), [n_ops] "s"(n_ops), [consts] "s"(consts), [n_consts] "s"(td.n_consts),
+                   [gslots] "s"(gslots), [gslot_bytes] "s"(gslot_bytes), [lds_base] "s"(lds_base), [lds_tab] "s"(lds_tab),
+                   [in_base] "s"(in_base), [out_base] "s"(out_base), [n4] "s"(n4), [live] "s"(live_mask),
+                   [evict_below] "s"(evict_below), [xbase] "s"(xbase), [v_lo] "v"(v_lo), [v_lo4] "v"(v_lo4),
+                   [v_vec4] "v"(v_vec4), [v_x] "v"(v_x), [v_x4] "v"(v_x4)
+                 : ZKIR_INTERP29_CORE_CLOBBERS);
+
+    if (lane == 0 && wave_unsat)
+      atomicAdd((unsigned long long*)&unsat_per_tape[td.unsat_index], (unsigned long long)wave_unsat);
+    if (live && first_bad != 0xffffffffu)
+      atomicMin((unsigned long long*)&stats[0], (unsigned long long)((vec << 32) | first_bad));
+  }
+}
+
+// constants of a tape in the form the 29-bit stream reads: canonical 8 x 32-bit words in, 12 words out
+// (9 limbs of 29 bits of c * 2^261 mod p, then 3 words of padding); src is not modified
+__global__ void zkir_consts_to_mont29_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t a[9];
+  const uint32_t r2[9] = {ZKIR_FR29_R2_LIMBS};
+  {  // unpack
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = src[(size_t)i * 8 + k];
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      const int bit = 29 * j, k = bit / 32, sh = bit % 32;
+      uint64_t v = w[k];
+      if (k + 1 < 8) v |= (uint64_t)w[k + 1] << 32;
+      a[j] = j < 8 ? (uint32_t)((v >> sh) & 0x1fffffffu) : (uint32_t)(v >> sh);
+    }
+  }
+  // product scanning with interleaved reduction: columns of a * r2 + m * p, 29 bits at a time
+  uint32_t m[9], r[9];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+      if (k - t >= 0 && k - t < 9) acc += (uint64_t)a[t] * r2[k - t];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+      if (t < k && k - t < 9) acc += (uint64_t)m[t] * zkir_p29[k - t];
+    if (k < 9) {
+      m[k] = ((uint32_t)acc * ZKIR_FR29_NP) & 0x1fffffffu;
+      acc += (uint64_t)m[k] * zkir_p29[0];
+    } else {
+      r[k - 9] = (uint32_t)acc & 0x1fffffffu;
+    }
+    acc >>= 29;
+  }
+  r[8] = (uint32_t)acc;
+#pragma unroll
+  for (int j = 0; j < 9; j++) dst[(size_t)i * 12 + j] = r[j];
+  dst[(size_t)i * 12 + 9] = dst[(size_t)i * 12 + 10] = dst[(size_t)i * 12 + 11] = 0;
+}
+
 // constants arrive canonical; rewrite them in Montgomery form in place
 __global__ void zkir_consts_to_mont_kernel(uint32_t* consts, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -479,11 +606,13 @@ __global__ void __launch_bounds__(256) zkir_fr_mul_rate_kernel(uint32_t* out, ui
 // ---- host-callable launchers (C++ linkage, used by runtime.cpp) ------------
 namespace zkir {
 
-// variant: 0 = + - * tapes (compiled), 1 = every operator (compiled), 2 = + - * tapes (generated stream)
+// variant: 0 = + - * tapes (compiled), 1 = every operator (compiled), 2 = + - * tapes (generated stream, 8 x 32-bit
+// limbs), 3 = + - * tapes (generated stream, 9 x 29-bit limbs)
 static const void* interp_entry(int variant) {
   switch (variant) {
     case 1: return (const void*)zkir_interp_kernel<true>;
     case 2: return (const void*)zkir_interp_lean_kernel;
+    case 3: return (const void*)zkir_interp_lean29_kernel;
     default: return (const void*)zkir_interp_kernel<false>;
   }
 }
@@ -492,14 +621,18 @@ static const void* interp_entry(int variant) {
 // not cost a resident workgroup (five fit a CU up to 32 KiB each).
 static bool interp_victim_row(int variant, uint32_t lslots, uint32_t strands) {
   static const bool off = std::getenv("ZKIR_NO_VICTIM_ROW") != nullptr;  // measurement aid
-  return variant == 2 && !strands && lslots + 1 <= 4 && !off;
+  if (strands || off) return false;
+  return (variant == 2 && lslots + 1 <= 4) || (variant == 3 && lslots + 1 <= 3);
 }
 // dynamic LDS of a workgroup: the window slots, plus the victim row, plus (strand tapes) the
 // exchange slots of 64 lanes x 32 bytes
 static size_t interp_lds_bytes(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots) {
-  return (size_t)(lslots + (interp_victim_row(variant, lslots, strands) ? 1 : 0)) * 2 * kBlock * sizeof(uint4) +
-         (strands ? (size_t)xslots * 2048 : 0);
+  const size_t rows = lslots + (interp_victim_row(variant, lslots, strands) ? 1 : 0);
+  if (variant == 3) return kTable29 + rows * kSlot29 + (strands ? (size_t)xslots * kWave29 : 0);
+  return rows * 2 * kBlock * sizeof(uint4) + (strands ? (size_t)xslots * 2048 : 0);
 }
+// bytes of one witness slot of one workgroup in device memory
+size_t interp_slot_bytes(int variant) { return variant == 3 ? kSlot29 : (size_t)2 * kBlock * sizeof(uint4); }
 
 hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
@@ -507,8 +640,9 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
                          uint32_t* work_counter, uint32_t grid, uint32_t strands, uint32_t xslots, hipStream_t stream) {
   const size_t lds_bytes = interp_lds_bytes(variant, lslots, strands, xslots);
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-  if (variant == 2 && n_vectors * 32 >= (1ull << 32)) return hipErrorInvalidValue;
-  if (strands && variant != 2) return hipErrorInvalidValue;  // only the generated stream knows strand tapes
+  if ((variant == 2 || variant == 3) && n_vectors * 32 >= (1ull << 32)) return hipErrorInvalidValue;
+  if ((variant == 2 || variant == 3) && (uint64_t)gslots_per_block * interp_slot_bytes(variant) >= (1ull << 32)) return hipErrorInvalidValue;
+  if (strands && variant != 2 && variant != 3) return hipErrorInvalidValue;  // only the generated streams know strand tapes
   if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS limit the kernel must opt in
     hipError_t e = hipFuncSetAttribute(interp_entry(variant), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -532,6 +666,12 @@ hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, uint32_t strands, 
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(zkir_consts_to_mont_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, consts_dev, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_consts_to_mont29(const uint32_t* canonical_dev, uint32_t* dst_dev, uint32_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(zkir_consts_to_mont29_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, canonical_dev, dst_dev, n);
   return hipGetLastError();
 }
 

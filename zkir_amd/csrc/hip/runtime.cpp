@@ -24,6 +24,8 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
                          uint32_t* work_counter, uint32_t grid, uint32_t strands, uint32_t xslots, hipStream_t stream);
 hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots, int* blocks);
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream);
+hipError_t launch_consts_to_mont29(const uint32_t* canonical_dev, uint32_t* dst_dev, uint32_t n, hipStream_t stream);
+size_t interp_slot_bytes(int variant);
 hipError_t launch_int_mul_rate(int which, uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
 hipError_t launch_fr_mul_rate(uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
 }  // namespace zkir
@@ -34,7 +36,8 @@ struct DevTape {
   zkir_tape_hdr hdr{};
   bool full = false;       // uses an operator beyond + - * : needs the full interpreter
   void* ops = nullptr;     // device
-  void* consts = nullptr;  // device, Montgomery form
+  void* consts = nullptr;  // device, Montgomery form (8 x 32-bit limbs, R = 2^256)
+  void* consts29 = nullptr;  // device, the same constants as 9 x 29-bit limbs with R = 2^261, 12 words each
   void* desc = nullptr;    // device: the TapeDesc of this tape evaluated alone (offsets 0, unsat index 0)
   int slab = -1;           // which slab of the context's tape arena holds ops, consts and desc
 };
@@ -184,6 +187,7 @@ TapeDesc make_desc(const DevTape& t, uint32_t index, uint64_t in_off, uint64_t o
   std::memset(&d, 0, sizeof d);
   d.ops = (const zkir_op*)t.ops;
   d.consts = (const uint32_t*)t.consts;
+  d.consts29 = (const uint32_t*)t.consts29;
   d.in_word_off = in_off;
   d.out_word_off = out_off;
   d.n_ops = t.hdr.n_ops;
@@ -217,18 +221,22 @@ uint32_t pick_grid(const zkir_ctx* ctx, uint64_t work_items, int variant, uint32
   return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, work_items));
 }
 
-constexpr size_t kSlotBytes = (size_t)2 * ZKIR_BLOCK_THREADS * 16;  // one witness slot of one workgroup: 8 KiB
+// one witness slot of one workgroup: 8 KiB, or 9 KiB in the kernel that keeps 9 limbs of 29 bits; the fixed
+// scratch of the no-alloc entry point is counted in rows of the larger size
+constexpr size_t kSlotBytesMax = 9216;
 
 // Which interpreter kernel runs a launch: 1 (compiled, every operator) when a tape uses an
-// operator beyond + - *; otherwise 2, the generated instruction stream, which addresses a
-// vector's data and a workgroup's slot region in 32 bits (32*N and 8192*gslots below 2^32);
-// otherwise 0, the compiled + - * kernel.  ZKIR_INTERP=compiled in the
-// environment forces the compiled kernels (a debugging aid: all three give the same bits).
+// operator beyond + - *; otherwise 3, the generated instruction stream on 9 x 29-bit limbs, which addresses
+// a vector's data and a workgroup's slot region in 32 bits (32*N and 9216*gslots below 2^32);
+// otherwise 0, the compiled + - * kernel.  ZKIR_INTERP in the environment forces another choice (a
+// debugging and measurement aid: all four give the same bits): "compiled" the compiled kernels,
+// "lean32" the generated stream on 8 x 32-bit limbs (variant 2).
 int pick_variant(bool full, uint64_t N, uint32_t max_gslots) {
   if (full) return 1;
   const char* want = std::getenv("ZKIR_INTERP");
   if (want && std::strcmp(want, "compiled") == 0) return 0;
-  return (N * 32 < (1ull << 32) && (uint64_t)max_gslots * kSlotBytes < (1ull << 32)) ? 2 : 0;
+  const int stream = (want && std::strcmp(want, "lean32") == 0) ? 2 : 3;
+  return (N * 32 < (1ull << 32) && (uint64_t)max_gslots * zkir::interp_slot_bytes(stream) < (1ull << 32)) ? stream : 0;
 }
 
 // The tapes of one kind in a call: plain tapes run 256 vectors per workgroup, strand tapes 64 (their
@@ -260,11 +268,14 @@ int32_t plan_group(zkir_ctx* ctx, const Group& G, int kind, uint64_t N, size_t p
   const uint64_t work = (uint64_t)G.count * P->passes;
   if (work >= (1ull << 32) - (1u << 20)) return fail(ctx, ZKIR_E_LIMIT, "too many (tape, pass) work items for one launch");
   P->variant = pick_variant(G.full, N, G.max_gslots);
+  if (kind && P->variant == 0) {  // ZKIR_INTERP=compiled: strand tapes still take a generated stream
+    const char* want = std::getenv("ZKIR_INTERP");
+    if (want && std::strcmp(want, "compiled") == 0 && (uint64_t)G.max_gslots * kSlotBytesMax < (1ull << 32)) P->variant = 3;
+  }
   if (kind) {  // only the generated stream runs strand tapes (upload refused any other operator)
     if (N * 32 >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 2^27 vectors per launch");
-    if ((uint64_t)G.max_gslots * kSlotBytes >= (1ull << 32))
-      return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 2^19 device slots per strand");
-    P->variant = 2;
+    if (P->variant != 2 && P->variant != 3)
+      return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 466 033 device slots per strand");
   }
   P->grid = pick_grid(ctx, work, P->variant, G.max_lslots, P->strands, G.max_xslots);
   if (pool_rows_cap && G.max_gslots) {
@@ -325,16 +336,16 @@ int32_t run_one(zkir_ctx* ctx, const DevTape& t, const uint32_t* in_dev, uint64_
   G.add(t);
   Plan P;
   const int kind = (t.hdr.flags & ZKIR_TAPE_F_STRANDS) ? 1 : 0;
-  const size_t rows_cap = fixed_scratch ? (fixed_bytes - kSlotBytes) / kSlotBytes : 0;
+  const size_t rows_cap = fixed_scratch ? (fixed_bytes - kSlotBytesMax) / kSlotBytesMax : 0;
   int32_t rc = plan_group(ctx, G, kind, N, rows_cap, &P);
   if (rc) return rc;
   void* pool = nullptr;
   uint32_t* counter = nullptr;
   if (fixed_scratch) {
     counter = (uint32_t*)fixed_scratch;
-    pool = fixed_scratch + kSlotBytes;
+    pool = fixed_scratch + kSlotBytesMax;
   } else {
-    rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, (size_t)P.grid * G.max_gslots * kSlotBytes);
+    rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, (size_t)P.grid * G.max_gslots * zkir::interp_slot_bytes(P.variant));
     if (rc) return rc;
     counter = (uint32_t*)ctx->work_counter;
     pool = ctx->gslot_pool;
@@ -404,7 +415,7 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
     if (!G[k].count) continue;
     rc = plan_group(ctx, G[k], k, N, 0, &plan[k]);
     if (rc) return rc;
-    pool_bytes = std::max(pool_bytes, (size_t)plan[k].grid * G[k].max_gslots * kSlotBytes);
+    pool_bytes = std::max(pool_bytes, (size_t)plan[k].grid * G[k].max_gslots * zkir::interp_slot_bytes(plan[k].variant));
   }
   rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, pool_bytes);
   if (rc) return rc;
@@ -528,10 +539,12 @@ int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hd
   if (consts_total / 32 >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "too many constants in one upload");
   const size_t consts_off = (ops_total + 255) & ~(size_t)255;
   const size_t descs_off = (consts_off + consts_total + 255) & ~(size_t)255;
-  const size_t total = descs_off + (size_t)n * sizeof(TapeDesc);
+  const size_t staged = descs_off + (size_t)n * sizeof(TapeDesc);  // what the host stages and copies
+  const size_t consts29_off = (staged + 255) & ~(size_t)255;       // written by the device: 48 bytes per constant
+  const size_t total = consts29_off + consts_total / 32 * 48;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   try {
-    staging.resize(total);
+    staging.resize(staged);
   } catch (const std::bad_alloc&) {
     return fail(ctx, ZKIR_E_NOMEM, "host staging buffer");
   }
@@ -547,6 +560,7 @@ int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hd
     if (cb) std::memcpy(staging.data() + c, (const char*)blobs[k] + ob, cb);
     tapes[k].ops = (char*)base + o;
     tapes[k].consts = (char*)base + c;
+    tapes[k].consts29 = (char*)base + consts29_off + (c - consts_off) / 32 * 48;
     tapes[k].desc = (char*)base + descs_off + (size_t)k * sizeof(TapeDesc);
     tapes[k].slab = slab;
     const TapeDesc d = make_desc(tapes[k], 0, 0, 0);
@@ -556,6 +570,11 @@ int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hd
   }
   // synchronous copy from pageable memory: `staging` may go when it returns
   hipError_t e = hipMemcpy(base, staging.data(), staging.size(), hipMemcpyHostToDevice);
+  // both forms of the constants: the 29-bit one is made from the canonical words first, then those are
+  // converted in place
+  if (e == hipSuccess)
+    e = zkir::launch_consts_to_mont29((const uint32_t*)((char*)base + consts_off), (uint32_t*)((char*)base + consts29_off),
+                                      (uint32_t)(consts_total / 32), nullptr);
   if (e == hipSuccess)
     e = zkir::launch_consts_to_mont((uint32_t*)((char*)base + consts_off), (uint32_t)(consts_total / 32), nullptr);
   if (e == hipSuccess) e = hipEventRecord(ctx->upload_done, nullptr);
