@@ -332,7 +332,11 @@ def main():
         value = checks_total / elapsed
         fr_muls = (h.n_mul_ops + h.n_constraints) * n  # per launch: one Montgomery product per Mul op and per check
         mulhi_peak = 1.0 if dry else ctx.int_mul_rate(0)
-        fr_peak = 1.0 if dry else ctx.fr_mul_rate()
+        want = os.environ.get("ZKIR_INTERP", "")
+        kernel = ("zkir_interp_kernel" if want == "compiled" else "zkir_interp_lean_kernel" if want == "lean32" else
+                  "zkir_interp_lean29_kernel" if want == "lean29" else
+                  "zkir_interp_lean_kernel" if h.n_gslots > 96 else "zkir_interp_lean29_kernel")  # the library's rule
+        fr_peak = 1.0 if dry else ctx.fr_mul_rate(limbs29=kernel == "zkir_interp_lean29_kernel")
         achieved = 128.0 * fr_muls / (kernel_ms * 1e-3)
         alg_bytes = (32 * (h.n_inputs + (h.n_outputs if want_outputs else 0)) + 4) * n
         # HBM bytes per launch from the counter passes committed under profiles/ (only for the
@@ -376,8 +380,7 @@ def main():
             },
             "fr_mul_per_s": fr_muls * world / (1e3 * elapsed / args.steps * 1e-3),
             "roofline": {
-                "kernel": ("zkir_interp_kernel" if os.environ.get("ZKIR_INTERP") == "compiled"
-                           else "zkir_interp_lean_kernel"),
+                "kernel": kernel,
                 "bound": "int32_mulhi",
                 "achieved": achieved / 1e12,
                 "peak": mulhi_peak / 1e12,

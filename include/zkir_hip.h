@@ -388,6 +388,10 @@ int32_t zkir_measure_int_mul_rate(zkir_ctx* ctx, int32_t which, double* lane_ops
  * (registers only, no tape): the ceiling of any tape made of ZKIR_OP_MUL. */
 int32_t zkir_measure_fr_mul_rate(zkir_ctx* ctx, double* fr_mul_per_s);
 
+/* The same for the multiplier on 9 limbs of 29 bits (Montgomery radix 2^261) that the interpreter
+ * uses for tapes whose values stay on chip. */
+int32_t zkir_measure_fr_mul_rate29(zkir_ctx* ctx, double* fr_mul_per_s);
+
 #ifdef __cplusplus
 }
 #endif

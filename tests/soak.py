@@ -48,7 +48,7 @@ for it in range(N):
     vecs = [[rnd.choice(special) if rnd.random() < 0.3 else rnd.randrange(F.P) for _ in range(tape.hdr.n_inputs)]
             for _ in range(nv)]
     inp = z.pack_inputs(vecs, tape.hdr.n_inputs)
-    for mode in ("", "lean32", "compiled"):
+    for mode in ("lean29", "lean32", "compiled"):
         if mode:
             os.environ["ZKIR_INTERP"] = mode
         else:

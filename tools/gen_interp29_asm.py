@@ -580,6 +580,34 @@ def build():
     return a.lines
 
 
+def rate_lines():
+    """Four Montgomery products per trip in registers, operands rotating through four register sets: the ceiling of
+    any tape made of products.  Operands: %[seed] (VGPR), %[iters] (SGPR, at least 1), result %[res] (VGPR)."""
+    out = []
+    X, Y, Z, W = A9, B9, ACC9, vreg9(VW)
+    for j in range(9):
+        out.append("v_mov_b32 %s, 0x%08x" % (P9[j], fr29.P_LIMBS[j]))
+    out.append("s_mov_b32 %s, 0x%08x" % (SNP0, fr29.NP))
+    out.append("s_mov_b32 %s, %%[iters]" % REM)
+    for regs, mul in ((X, 0x9E3779B1), (Y, 0x85EBCA77)):
+        for j in range(9):
+            out.append("v_mul_lo_u32 %s, %%[seed], %s" % (regs[j], P9[j]))
+            out.append("v_add_u32 %s, 0x%x, %s" % (regs[j], (mul * (j + 1)) & 0xFFFFFFF, regs[j]))
+            out.append("v_and_b32 %s, 0x%x, %s" % (regs[j], fr29.MASK if j < 8 else 0x1FFFFF, regs[j]))
+    out.append(".Lz29_rate_top:")
+    fr29.mul29(out, X, Y, Z, M9, ACCN, P9, SNP0, CS)
+    fr29.mul29(out, Y, Z, W, M9, ACCN, P9, SNP0, CS)
+    fr29.mul29(out, Z, W, X, M9, ACCN, P9, SNP0, CS)
+    fr29.mul29(out, W, X, Y, M9, ACCN, P9, SNP0, CS)
+    out.append("s_sub_u32 %s, %s, 1" % (REM, REM))
+    out.append("s_cmp_lg_u32 %s, 0" % REM)
+    out.append("s_cbranch_scc1 .Lz29_rate_top")
+    out.append("v_mov_b32 %%[res], %s" % X[0])
+    for r in X[1:] + Y:
+        out.append("v_xor_b32 %%[res], %%[res], %s" % r)
+    return out
+
+
 def clobbers():
     v = ['"v%d"' % k for k in range(VB, V_LAST + 1)]
     s = ['"s%d"' % k for k in range(SB, S_LAST + 1)]
@@ -599,6 +627,11 @@ def render(lines):
     out.append("#define ZKIR_FR29_R2_LIMBS %s" % ", ".join("0x%08xu" % v for v in R2_29))
     out.append("#define ZKIR_FR29_NP 0x%08xu" % fr29.NP)
     out.append("#define ZKIR_INTERP29_CORE_VGPR_LAST %d" % V_LAST)
+    out.append("// four products per trip in registers (the rate probe); same clobber list")
+    out.append("#define ZKIR_FR29_RATE_ASM \\")
+    for l in rate_lines():
+        out.append('  "%s\\n" \\' % l)
+    out.append("")
     return "\n".join(out) + "\n"
 
 

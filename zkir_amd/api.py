@@ -96,6 +96,7 @@ def _load():
         "zkir_last_faults": [c_void_p, P(c_uint64)],
         "zkir_measure_int_mul_rate": [c_void_p, c_int32, P(c_double)],
         "zkir_measure_fr_mul_rate": [c_void_p, P(c_double)],
+        "zkir_measure_fr_mul_rate29": [c_void_p, P(c_double)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -395,9 +396,10 @@ class Context:
         self._check(lib.zkir_measure_int_mul_rate(self._h, which, byref(d)))
         return d.value
 
-    def fr_mul_rate(self):
+    def fr_mul_rate(self, limbs29=False):
+        """Montgomery products per second in registers: the 8 x 32-bit multiplier, or the 9 x 29-bit one."""
         d = c_double()
-        self._check(lib.zkir_measure_fr_mul_rate(self._h, byref(d)))
+        self._check((lib.zkir_measure_fr_mul_rate29 if limbs29 else lib.zkir_measure_fr_mul_rate)(self._h, byref(d)))
         return d.value
 
 

@@ -28,6 +28,7 @@ hipError_t launch_consts_to_mont29(const uint32_t* canonical_dev, uint32_t* dst_
 size_t interp_slot_bytes(int variant);
 hipError_t launch_int_mul_rate(int which, uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
 hipError_t launch_fr_mul_rate(uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
+hipError_t launch_fr29_mul_rate(uint32_t* out, uint32_t blocks, int iters, hipStream_t stream);
 }  // namespace zkir
 
 using zkir::TapeDesc;
@@ -228,14 +229,21 @@ constexpr size_t kSlotBytesMax = 9216;
 // Which interpreter kernel runs a launch: 1 (compiled, every operator) when a tape uses an
 // operator beyond + - *; otherwise 3, the generated instruction stream on 9 x 29-bit limbs, which addresses
 // a vector's data and a workgroup's slot region in 32 bits (32*N and 9216*gslots below 2^32);
-// otherwise 0, the compiled + - * kernel.  ZKIR_INTERP in the environment forces another choice (a
-// debugging and measurement aid: all four give the same bits): "compiled" the compiled kernels,
-// "lean32" the generated stream on 8 x 32-bit limbs (variant 2).
+// otherwise 0, the compiled + - * kernel.  Tapes that keep more than kSpillHeavySlots values in device
+// memory take variant 2 instead, the generated stream on 8 x 32-bit limbs: such launches run at the rate
+// device memory delivers their witness slots, and a 32-byte slot moves 11 % fewer bytes than a 36-byte one
+// (measured on the 1 047-constraint circuit with 430 slots: 30.8 ms against 31.6; on the gadget, which
+// keeps its values on chip, the 29-bit stream is 1.2 to 1.3 times faster).  ZKIR_INTERP in the
+// environment forces a choice (a debugging and measurement aid: all four kernels give the same bits):
+// "compiled", "lean32" (variant 2), "lean29" (variant 3).
+constexpr uint32_t kSpillHeavySlots = 96;
 int pick_variant(bool full, uint64_t N, uint32_t max_gslots) {
   if (full) return 1;
   const char* want = std::getenv("ZKIR_INTERP");
   if (want && std::strcmp(want, "compiled") == 0) return 0;
-  const int stream = (want && std::strcmp(want, "lean32") == 0) ? 2 : 3;
+  int stream = max_gslots > kSpillHeavySlots ? 2 : 3;
+  if (want && std::strcmp(want, "lean32") == 0) stream = 2;
+  if (want && std::strcmp(want, "lean29") == 0) stream = 3;
   return (N * 32 < (1ull << 32) && (uint64_t)max_gslots * zkir::interp_slot_bytes(stream) < (1ull << 32)) ? stream : 0;
 }
 
@@ -773,7 +781,8 @@ int32_t zkir_last_faults(const zkir_ctx* ctx, uint64_t* faults) {
   return ZKIR_OK;
 }
 
-static int32_t time_probe(zkir_ctx* ctx, int which, bool fr, double* out) {
+// which: the multiply instruction of the integer probe; fr: 0 = that probe, 1 = the 8 x 32-bit multiplier, 2 = the 9 x 29-bit one
+static int32_t time_probe(zkir_ctx* ctx, int which, int fr, double* out) {
   if (!ctx || !out) return ZKIR_E_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t blocks = (uint32_t)ctx->n_cu * 8;  // 8 waves per SIMD
@@ -787,8 +796,9 @@ static int32_t time_probe(zkir_ctx* ctx, int which, bool fr, double* out) {
     return fail(ctx, ZKIR_E_HIP, "rate probe: hipEventCreate failed");
   }
   auto launch = [&]() {
-    return fr ? zkir::launch_fr_mul_rate(buf, blocks, iters, nullptr)
-              : zkir::launch_int_mul_rate(which, buf, blocks, iters, nullptr);
+    return fr == 2 ? zkir::launch_fr29_mul_rate(buf, blocks, iters, nullptr)
+           : fr  ? zkir::launch_fr_mul_rate(buf, blocks, iters, nullptr)
+                 : zkir::launch_int_mul_rate(which, buf, blocks, iters, nullptr);
   };
   hipError_t e = launch();
   if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -812,9 +822,11 @@ static int32_t time_probe(zkir_ctx* ctx, int which, bool fr, double* out) {
 
 int32_t zkir_measure_int_mul_rate(zkir_ctx* ctx, int32_t which, double* lane_ops_per_s) {
   if (which < 0 || which > 2) return ZKIR_E_INVALID;
-  return time_probe(ctx, which, false, lane_ops_per_s);
+  return time_probe(ctx, which, 0, lane_ops_per_s);
 }
 
-int32_t zkir_measure_fr_mul_rate(zkir_ctx* ctx, double* fr_mul_per_s) { return time_probe(ctx, 0, true, fr_mul_per_s); }
+int32_t zkir_measure_fr_mul_rate(zkir_ctx* ctx, double* fr_mul_per_s) { return time_probe(ctx, 0, 1, fr_mul_per_s); }
+
+int32_t zkir_measure_fr_mul_rate29(zkir_ctx* ctx, double* fr_mul_per_s) { return time_probe(ctx, 0, 2, fr_mul_per_s); }
 
 }  // extern "C"
