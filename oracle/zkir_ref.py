@@ -537,13 +537,15 @@ class Interpreter:
     def unsat(self):
         return [k for k, (a, b, c) in enumerate(self.constraints) if F.mul(a, b) != c]
 
-    # expressions: returns (value, degree, quad) with quad = (A, B, [(coef, value)]) for degree 2
+    # expressions: returns (value, degree, quad, from_signal) with quad = (A, B, [(coef, value)]) for degree 2;
+    # from_signal: the value derives from a signal, so circom does not know it at compile time even where this
+    # interpreter does (a signal constrained to a constant): it may not decide a condition or an index
     def ev(self, e):
         k = e[0]
         if k == "const":
             if not re.fullmatch(r"[0-9]+", e[1]):
                 raise Rejected("BadAst", "constant")
-            return (int(e[1]) % F.P, KNOWN, None)
+            return (int(e[1]) % F.P, KNOWN, None, False)
         if k == "var":
             v = self.vars.get(e[1])
             if v is None or not v["declared"]:
@@ -562,8 +564,9 @@ class Interpreter:
                 raise Rejected("UninitSignal", v["name"])
             return c
         a = self.ev(e[1])
-        b = self.ev(e[2]) if k != "bnot" else (0, KNOWN, None)
+        b = self.ev(e[2]) if k != "bnot" else (0, KNOWN, None, False)
         both_known = a[1] == KNOWN and b[1] == KNOWN
+        sig = a[3] or b[3]
         if k in ("div", "idiv", "rem") and b[1] == KNOWN and b[0] == 0:
             raise Rejected("DivByZero")
         try:
@@ -572,7 +575,7 @@ class Interpreter:
             val = 0
             self.faults = 1
         if both_known:
-            return (val, KNOWN, None)
+            return (val, KNOWN, None, sig)
         da, db = a[1], b[1]
         deg, quad = NONQUAD, None
         if k in ("add", "sub"):
@@ -608,11 +611,11 @@ class Interpreter:
                 deg = QUADRATIC
                 s, A, B, terms = a[2]
                 quad = (F.mul(s, inv), A, B, [(F.mul(c, inv), x) for c, x in terms])
-        return (val, deg, quad)
+        return (val, deg, quad, sig)
 
     def truth(self, e):
         v = self.ev(e)
-        if v[1] != KNOWN:
+        if v[1] != KNOWN or v[3]:
             raise Rejected("UnknownControl")
         return v[0] != 0
 
@@ -636,10 +639,10 @@ class Interpreter:
             v["declared"] += 1
             n = v["array_len"] if v["array_len"] is not None else 1
             if v["role"] == "local":
-                v["cells"] = [(0, KNOWN, None)] * n  # circom variables start at 0
+                v["cells"] = [(0, KNOWN, None, False)] * n  # circom variables start at 0
             elif v["role"] == "input":
                 base = self.in_map[v["id"]]
-                v["cells"] = [(self.inputs[base + j], LINEAR, None) for j in range(n)]
+                v["cells"] = [(self.inputs[base + j], LINEAR, None, True) for j in range(n)]
             else:
                 v["cells"] = [None] * n
             if i[2] is not None:
@@ -656,7 +659,7 @@ class Interpreter:
             if v is None or v["role"] != "local" or v["array_len"] is None or not v["declared"]:
                 raise Rejected("BadAst", "array assign target")
             idx = self.ev(i[2])
-            if idx[1] != KNOWN:
+            if idx[1] != KNOWN or idx[3]:
                 raise Rejected("UnknownControl", "index")
             if idx[0] >= v["array_len"]:
                 raise Rejected("OOBIndex", v["name"])
@@ -686,7 +689,7 @@ class Interpreter:
                 self.constraints.append((F.mul(s, A), B, F.sub(val[0], lin)))
             else:
                 self.constraints.append((val[0], 1, val[0]))
-            v["cells"][j] = (val[0], KNOWN if val[1] == KNOWN else LINEAR, None)
+            v["cells"][j] = (val[0], KNOWN if val[1] == KNOWN else LINEAR, None, True)
         elif k == "if":
             if self.truth(i[1]):
                 self.block(i[2])

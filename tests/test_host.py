@@ -313,6 +313,17 @@ def test_lower_classes_by_hand():
         ref = R.parse_text(text)
         tape, cls, it, rcls = classify_and_values(text, ref, [5, 6], 1, cap=500)
         assert cls == want and rcls == want, (want, cls, rcls)
+    # a signal constrained to a constant is still a signal: its value decides neither a condition nor an index
+    for stmt in ('(constrain 2 (const "5")) (if (eq (var 2) (const "5")) (then (assign 3 (const "1"))))',
+                 '(constrain 2 (const "1")) (aassign 4 (var 2) (const "7"))',
+                 '(constrain 2 (const "2")) (assign 3 (add (var 2) (const "1"))) (while (lt (var 3) (const "2")) (body (assign 3 (const "9"))))'):
+        text = base % stmt
+        tape, cls, it, rcls = classify_and_values(text, R.parse_text(text), [5, 6], 1)
+        assert cls == rcls == "UnknownControl", (stmt, cls, rcls)
+    # ... while arithmetic on it is still folded where that is allowed
+    text = base % '(constrain 2 (const "5")) (constrain (5 0) (mul (var 2) (var 0)))'
+    tape, cls, it, rcls = classify_and_values(text, R.parse_text(text), [5, 6], 1)
+    assert cls == rcls == "OK" and it.outputs[1] == 25
     # division by a known constant keeps the degree (x / k == x * k^-1)
     text = base % '(constrain 2 (div (mul (var 0) (var 1)) (const "7")))'
     tape, cls, it, rcls = classify_and_values(text, R.parse_text(text), [5, 6], 1)

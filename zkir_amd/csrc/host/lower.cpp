@@ -55,6 +55,8 @@ struct Term {
 struct Val {
   bool assigned = false;  // false: an output signal nothing has been assigned to yet
   bool known = false;     // value is fixed at lowering time
+  bool from_signal = false;  // derives from a signal: circom does not know it at compile time even where this
+                             // pass does (a signal constrained to a constant), so it may not decide a condition or an index
   U256 value;             // when known
   Ref ref = kNoRef;       // where the tape holds it (may be absent for a folded known value)
   Degree deg = kKnown;
@@ -326,6 +328,7 @@ class Pass1 {
     const uint8_t code = opcode_of(e.kind, opts_.bnot_variant);
     Val r;
     r.assigned = true;
+    r.from_signal = a.from_signal || b.from_signal;
     if (a.known && b.known) {
       r.known = true;
       r.deg = kKnown;
@@ -337,6 +340,7 @@ class Pass1 {
         b.value.is_zero())
       fail(ZKIR_LOWER_DIV_BY_ZERO, "division by a known zero");
     combine(e.kind, a, b, &r);
+    r.from_signal = a.from_signal || b.from_signal;
     r.ref = new_value(code, ref_of(a), e.is_binary() ? ref_of(b) : kNoRef);
     return r;
   }
@@ -354,6 +358,7 @@ class Pass1 {
       for (Val& v : c.cell) {
         v.assigned = true;
         v.deg = kLinear;
+        v.from_signal = true;
       }
     }
     if (ins.default_value) {
@@ -374,7 +379,7 @@ class Pass1 {
     if (!c.var.role.is_local() || !c.var.var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "ArrayAssign target must be a local array");
     if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "assignment before declaration");
     Val idx = eval(*ins.index);
-    if (!idx.known) fail(ZKIR_LOWER_UNKNOWN_CONTROL, "array index depends on a signal");
+    if (!idx.known || idx.from_signal) fail(ZKIR_LOWER_UNKNOWN_CONTROL, "array index depends on a signal");
     if (idx.value.w[1] | idx.value.w[2] | idx.value.w[3] || idx.value.w[0] >= c.cell.size())
       fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var.name);
     Val v = eval(*ins.value);
@@ -426,6 +431,7 @@ class Pass1 {
     Val sig;
     sig.assigned = true;
     sig.known = v.known;
+    sig.from_signal = true;
     sig.value = v.value;
     sig.ref = out;
     sig.deg = v.known ? kKnown : kLinear;
@@ -434,7 +440,7 @@ class Pass1 {
 
   bool truth(const Expr& cond, const char* what) {
     Val v = eval(cond);
-    if (!v.known) fail(ZKIR_LOWER_UNKNOWN_CONTROL, std::string(what) + " condition depends on a signal");
+    if (!v.known || v.from_signal) fail(ZKIR_LOWER_UNKNOWN_CONTROL, std::string(what) + " condition depends on a signal");
     return !v.value.is_zero();
   }
 
