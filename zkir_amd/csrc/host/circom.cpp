@@ -46,7 +46,7 @@ std::string CircomTranspiler::transpile_expr(const Expr& e) const {
       return var.name;
     }
     case ExprKind::Constant:
-      return e.constant;
+      return e.constant.str();
     case ExprKind::BitNot:
       return "(~" + transpile_expr(*e.left) + ")";  // circom.rs:136
     default:
@@ -102,41 +102,42 @@ std::string CircomTranspiler::transpile_instruction(const Instruction& instr) {
     case InstrKind::If: {
       std::string res = get_indent() + "if (" + transpile_expr(*instr.cond) + ") {\n";
       indent_size_ += 1;
-      res += transpile_block(instr.then_branch) + "\n";
+      res += transpile_block(instr.then_branch()) + "\n";
       indent_size_ -= 1;
-      if (instr.else_branch) {
+      if (instr.else_branch()) {
         res += get_indent() + "} else {\n";
         indent_size_ += 1;
-        res += transpile_block(*instr.else_branch) + "\n";
+        res += transpile_block(*instr.else_branch()) + "\n";
         indent_size_ -= 1;
       }
       res += get_indent() + "}";
       return res;
     }
     case InstrKind::For: {
-      if (!(instr.init->kind == InstrKind::Assign || instr.init->kind == InstrKind::VarDecl))
+      if (!instr.init() || !instr.step()) throw std::logic_error("For-loop without init or step");
+      if (!(instr.init()->kind == InstrKind::Assign || instr.init()->kind == InstrKind::VarDecl))
         throw std::logic_error("For-loop inits must be an assignment");
-      if (instr.step->kind != InstrKind::Assign) throw std::logic_error("For-loop steps must be an assignment");
-      if (instr.body.empty()) throw std::logic_error("Empty for loop bodies are not allowed");
+      if (instr.step()->kind != InstrKind::Assign) throw std::logic_error("For-loop steps must be an assignment");
+      if (instr.body().empty()) throw std::logic_error("Empty for loop bodies are not allowed");
       // init keeps its `;`, step loses every `;` (circom.rs:354-362)
-      std::string init = trim(transpile_instruction(*instr.init));
+      std::string init = trim(transpile_instruction(*instr.init()));
       std::string cond = transpile_expr(*instr.cond);
-      std::string step_raw = transpile_instruction(*instr.step), step;
+      std::string step_raw = transpile_instruction(*instr.step()), step;
       for (char ch : step_raw)
         if (ch != ';') step.push_back(ch);
       step = trim(step);
       std::string res = get_indent() + "for (" + init + " " + cond + "; " + step + ") {\n";
       indent_size_ += 1;
-      res += transpile_block(instr.body) + "\n";
+      res += transpile_block(instr.body()) + "\n";
       indent_size_ -= 1;
       res += get_indent() + "}";
       return res;
     }
     case InstrKind::While: {
-      if (instr.body.empty()) throw std::logic_error("Empty while loop bodies are not allowed");
+      if (instr.body().empty()) throw std::logic_error("Empty while loop bodies are not allowed");
       std::string res = get_indent() + "while (" + transpile_expr(*instr.cond) + ") {\n";
       indent_size_ += 1;
-      res += transpile_block(instr.body) + "\n";
+      res += transpile_block(instr.body()) + "\n";
       indent_size_ -= 1;
       res += get_indent() + "}";
       return res;
@@ -225,7 +226,7 @@ void dbg_expr(Dbg& d, const Expr& e) {
   if (e.kind == ExprKind::Var) {
     d.pad(); dbg_varref(d, e.var); d.item_end();
   } else if (e.kind == ExprKind::Constant) {
-    d.pad(); d.out += quote(e.constant); d.item_end();
+    d.pad(); d.out += quote(e.constant.str()); d.item_end();
   } else {
     d.pad(); dbg_expr(d, *e.left); d.item_end();
     if (e.right) { d.pad(); dbg_expr(d, *e.right); d.item_end(); }
@@ -272,7 +273,7 @@ void dbg_vec(Dbg& d, const std::vector<Instruction>& v) {
   d.close("]");
 }
 
-void dbg_opt_expr(Dbg& d, const std::optional<Expr>& e) {
+void dbg_opt_expr(Dbg& d, const Expr* e) {
   if (!e) { d.out += "None"; return; }
   d.open("Some(");
   d.pad(); dbg_expr(d, *e); d.item_end();
@@ -309,11 +310,11 @@ void dbg_instr(Dbg& d, const Instruction& i) {
     case InstrKind::If:
       d.open("If {");
       d.pad(); d.out += "cond: "; dbg_expr(d, *i.cond); d.item_end();
-      d.pad(); d.out += "then_branch: "; dbg_vec(d, i.then_branch); d.item_end();
+      d.pad(); d.out += "then_branch: "; dbg_vec(d, i.then_branch()); d.item_end();
       d.pad(); d.out += "else_branch: ";
-      if (i.else_branch) {
+      if (i.else_branch()) {
         d.open("Some(");
-        d.pad(); dbg_vec(d, *i.else_branch); d.item_end();
+        d.pad(); dbg_vec(d, *i.else_branch()); d.item_end();
         d.close(")");
       } else {
         d.out += "None";
@@ -323,16 +324,16 @@ void dbg_instr(Dbg& d, const Instruction& i) {
       break;
     case InstrKind::For:
       d.open("For {");
-      d.pad(); d.out += "init: "; dbg_instr(d, *i.init); d.item_end();
+      d.pad(); d.out += "init: "; dbg_instr(d, *i.init()); d.item_end();
       d.pad(); d.out += "cond: "; dbg_expr(d, *i.cond); d.item_end();
-      d.pad(); d.out += "step: "; dbg_instr(d, *i.step); d.item_end();
-      d.pad(); d.out += "body: "; dbg_vec(d, i.body); d.item_end();
+      d.pad(); d.out += "step: "; dbg_instr(d, *i.step()); d.item_end();
+      d.pad(); d.out += "body: "; dbg_vec(d, i.body()); d.item_end();
       d.close("}");
       break;
     case InstrKind::While:
       d.open("While {");
       d.pad(); d.out += "cond: "; dbg_expr(d, *i.cond); d.item_end();
-      d.pad(); d.out += "body: "; dbg_vec(d, i.body); d.item_end();
+      d.pad(); d.out += "body: "; dbg_vec(d, i.body()); d.item_end();
       d.close("}");
       break;
   }

@@ -22,11 +22,12 @@ Circuit poseidon_style_gadget(uint32_t width, uint32_t rounds, uint64_t seed) {
     v.name = name;
     v.var_type = VariableType::Field();
     v.role = role;
-    v.initialized = {false};
+    v.initialized.assign(1, false);
     c.variables.push_back(v);
     return v;
   };
-  auto cst = [&]() { return Expr::Constant(std::to_string(rng.next())); };
+  Arena& ar = *c.arena;
+  auto cst = [&]() { return Expr::Constant(rng.next()); };
   auto var = [](const Variable& v) { return Expr::Var(v.var_ref); };
 
   std::vector<Expr> mix;  // width x width constants, reused by every round
@@ -35,9 +36,9 @@ Circuit poseidon_style_gadget(uint32_t width, uint32_t rounds, uint64_t seed) {
   std::vector<Variable> state;
   for (uint32_t i = 0; i < width; i++) {
     Variable in = add_var("in" + std::to_string(i), VariableRole::Signal(SignalType::Input));
-    c.instructions.push_back(Instruction::VarDecl(in, std::nullopt));
+    c.instructions.push_back(Instruction::VarDecl(ar, in, std::nullopt));
     Variable s = add_var("s" + std::to_string(i), VariableRole::Local());
-    c.instructions.push_back(Instruction::VarDecl(s, var(in)));
+    c.instructions.push_back(Instruction::VarDecl(ar, s, var(in)));
     state.push_back(s);
   }
   for (uint32_t r = 0; r < rounds; r++) {
@@ -47,27 +48,27 @@ Circuit poseidon_style_gadget(uint32_t width, uint32_t rounds, uint64_t seed) {
       const std::string t = tag + std::to_string(i);
       // a = s + round constant
       Variable a = add_var("a" + t, VariableRole::Local());
-      c.instructions.push_back(Instruction::VarDecl(a, Expr::Binary(ExprKind::Add, var(state[i]), cst())));
+      c.instructions.push_back(Instruction::VarDecl(ar, a, Expr::Binary(ar, ExprKind::Add, var(state[i]), cst())));
       // x^5 as three rank-1 constraints: sq = a*a, qd = sq*sq, ft = qd*a
       Variable sq = add_var("sq" + t, VariableRole::Signal(SignalType::Output));
-      c.instructions.push_back(Instruction::VarDecl(sq, std::nullopt));
-      c.instructions.push_back(Instruction::Constraint(sq.var_ref, Expr::Binary(ExprKind::Mul, var(a), var(a))));
+      c.instructions.push_back(Instruction::VarDecl(ar, sq, std::nullopt));
+      c.instructions.push_back(Instruction::Constraint(ar, sq.var_ref, Expr::Binary(ar, ExprKind::Mul, var(a), var(a))));
       Variable qd = add_var("qd" + t, VariableRole::Signal(SignalType::Output));
-      c.instructions.push_back(Instruction::VarDecl(qd, std::nullopt));
-      c.instructions.push_back(Instruction::Constraint(qd.var_ref, Expr::Binary(ExprKind::Mul, var(sq), var(sq))));
+      c.instructions.push_back(Instruction::VarDecl(ar, qd, std::nullopt));
+      c.instructions.push_back(Instruction::Constraint(ar, qd.var_ref, Expr::Binary(ar, ExprKind::Mul, var(sq), var(sq))));
       Variable ft = add_var("ft" + t, VariableRole::Signal(SignalType::Output));
-      c.instructions.push_back(Instruction::VarDecl(ft, std::nullopt));
-      c.instructions.push_back(Instruction::Constraint(ft.var_ref, Expr::Binary(ExprKind::Mul, var(qd), var(a))));
+      c.instructions.push_back(Instruction::VarDecl(ar, ft, std::nullopt));
+      c.instructions.push_back(Instruction::Constraint(ar, ft.var_ref, Expr::Binary(ar, ExprKind::Mul, var(qd), var(a))));
       sboxed.push_back(ft);
     }
     // dense mix: s_i = sum_j M[i][j] * ft_j
     std::vector<Variable> next;
     for (uint32_t i = 0; i < width; i++) {
-      Expr acc = Expr::Binary(ExprKind::Mul, mix[i * width], var(sboxed[0]));
+      Expr acc = Expr::Binary(ar, ExprKind::Mul, mix[i * width], var(sboxed[0]));
       for (uint32_t j = 1; j < width; j++)
-        acc = Expr::Binary(ExprKind::Add, std::move(acc), Expr::Binary(ExprKind::Mul, mix[i * width + j], var(sboxed[j])));
+        acc = Expr::Binary(ar, ExprKind::Add, acc, Expr::Binary(ar, ExprKind::Mul, mix[i * width + j], var(sboxed[j])));
       Variable s = add_var("m" + tag + std::to_string(i), VariableRole::Local());
-      c.instructions.push_back(Instruction::VarDecl(s, std::move(acc)));
+      c.instructions.push_back(Instruction::VarDecl(ar, s, acc));
       next.push_back(s);
     }
     state = next;

@@ -62,8 +62,7 @@ void Generator::ScopeStack::refresh(size_t pos) {
   const bool field = !v.var_type.is_array;
   ready_fields.set(pos, field && v.all_initialized());
   open_outputs.set(pos, v.role.is_output() && field && !v.all_initialized());
-  uint32_t written = 0;
-  for (bool b : v.initialized) written += b;
+  const uint32_t written = (uint32_t)v.initialized.count();
   written_count[pos] = written;
   const bool touched = !field && written > 0;
   if (touched && !touched_arrays.test(pos))  // first write to this array: keep the list ascending
@@ -73,7 +72,7 @@ void Generator::ScopeStack::refresh(size_t pos) {
 }
 
 Variable Generator::ScopeStack::add_var(std::string name, VariableType t, VariableRole r,
-                                        std::vector<bool> initialized) {
+                                        InitFlags initialized) {
   Variable var;
   var.var_ref.id = next_id;
   var.name = std::move(name);
@@ -120,7 +119,7 @@ void Generator::ScopeStack::mark_initialized(const VarRef& var_id) {
   if (lo == flat.size() || flat[lo].var_ref.id != var_id.id) return;  // not in scope: nothing to mark (generator.rs:101-114)
   Variable& var = flat[lo];
   if (var_id.idx)
-    var.initialized.at(*var_id.idx) = true;
+    var.initialized.set(*var_id.idx, true);
   else
     var.initialized.assign(1, true);
   refresh(lo);
@@ -159,7 +158,7 @@ Circuit Generator::generate() {
 
   scope_stack_.leave_scope();
   if (!scope_stack_.empty()) throw std::logic_error("scope stack not empty");  // generator.rs:161
-  return Circuit(std::move(scope_stack_.all_vars), std::move(instructions));  // a Generator is single use
+  return Circuit(std::move(scope_stack_.all_vars), std::move(instructions), arena_);  // a Generator is single use
 }
 
 std::optional<Instruction> Generator::generate_instr() {
@@ -172,15 +171,16 @@ std::optional<Instruction> Generator::generate_instr() {
 
   // candidate order of generator.rs:188-204
   enum Cand { kVarDecl, kIf, kFor, kAssign, kArrayAssign, kConstraint };
-  std::vector<Cand> funcs;
-  funcs.push_back(kVarDecl);
-  if (cfg_.enable_if) funcs.push_back(kIf);  // extension: the reference keeps this entry commented out (:190)
-  if (!cfg_.no_loops) funcs.push_back(kFor);
-  if (has_vars) funcs.push_back(kAssign);
-  if (has_arrays) funcs.push_back(kArrayAssign);
-  if (has_output_signals || cfg_.quadratic_aware) funcs.push_back(kConstraint);
+  Cand funcs[6];
+  size_t n_funcs = 0;
+  funcs[n_funcs++] = kVarDecl;
+  if (cfg_.enable_if) funcs[n_funcs++] = kIf;  // extension: the reference keeps this entry commented out (:190)
+  if (!cfg_.no_loops) funcs[n_funcs++] = kFor;
+  if (has_vars) funcs[n_funcs++] = kAssign;
+  if (has_arrays) funcs[n_funcs++] = kArrayAssign;
+  if (has_output_signals || cfg_.quadratic_aware) funcs[n_funcs++] = kConstraint;
 
-  const size_t idx = rng_.rand(0, funcs.size() - 1);
+  const size_t idx = rng_.rand(0, n_funcs - 1);
   switch (funcs[idx]) {
     case kVarDecl: return gen_var_decl_default();
     case kIf: return gen_if();
@@ -232,11 +232,11 @@ std::optional<Instruction> Generator::gen_var_decl(std::optional<VariableType> t
   // all false even when a default is present (generator.rs:255-260); the extension
   // makes input signals readable from the start
   const bool readable = cfg_.inputs_readable && role.is_input();
-  std::vector<bool> initialized(var_type.is_array ? var_type.len : 1, readable);
+  InitFlags initialized(var_type.is_array ? var_type.len : 1, readable);
 
   std::string name = rng_.rand_string(cfg_.name_len);
   Variable v = scope_stack_.add_var(std::move(name), var_type, role, std::move(initialized));
-  return Instruction::VarDecl(std::move(v), std::move(default_value));
+  return Instruction::VarDecl(*arena_, std::move(v), default_value);
 }
 
 std::optional<Instruction> Generator::gen_assign() {
@@ -249,7 +249,7 @@ std::optional<Instruction> Generator::gen_assign() {
   if (!expr) return std::nullopt;
 
   scope_stack_.mark_initialized(var_id);
-  return Instruction::Assign(var_id, std::move(*expr));
+  return Instruction::Assign(*arena_, var_id, *expr);
 }
 
 std::optional<Instruction> Generator::gen_array_assign() {
@@ -264,7 +264,7 @@ std::optional<Instruction> Generator::gen_array_assign() {
       marked.id = var_ref.id;
       marked.idx = idx;
       scope_stack_.mark_initialized(marked);
-      return Instruction::ArrayAssign(var_ref, Expr::Constant(std::to_string(idx)), std::move(*expr));
+      return Instruction::ArrayAssign(*arena_, var_ref, Expr::Constant((uint64_t)idx), *expr);
     }
   }
   return std::nullopt;
@@ -278,7 +278,7 @@ std::optional<Instruction> Generator::gen_constraint() {
     // marked before the right-hand side is generated (generator.rs:344-346): `out <== out` is reachable
     scope_stack_.mark_initialized(var_id);
     std::optional<Expr> expr = generate_expr(0);
-    if (expr) return Instruction::Constraint(var_id, std::move(*expr));
+    if (expr) return Instruction::Constraint(*arena_, var_id, *expr);
   }
   return std::nullopt;
 }
@@ -289,9 +289,9 @@ std::optional<Instruction> Generator::gen_if() {
     // extension: a comparison of two constants, decidable when the circuit is lowered
     static const ExprKind kCmp[] = {ExprKind::LessThan, ExprKind::Equal, ExprKind::GreaterThan};
     const ExprKind k = kCmp[rng_.rand(0, 2)];
-    Expr l = Expr::Constant(std::to_string(rng_.next()));
-    Expr r = Expr::Constant(std::to_string(rng_.next()));
-    cond = Expr::Binary(k, std::move(l), std::move(r));
+    Expr l = Expr::Constant(rng_.next());
+    Expr r = Expr::Constant(rng_.next());
+    cond = Expr::Binary(*arena_, k, l, r);
   } else {
     cond = generate_expr(0);
   }
@@ -311,7 +311,7 @@ std::optional<Instruction> Generator::gen_if() {
     if (!instrs.empty()) else_branch = std::move(instrs);
   }
   scope_stack_.leave_scope();
-  return Instruction::If(std::move(*cond), std::move(then_branch), std::move(else_branch));
+  return Instruction::If(*arena_, *cond, std::move(then_branch), std::move(else_branch));
 }
 
 std::optional<Instruction> Generator::gen_for() {
@@ -320,20 +320,20 @@ std::optional<Instruction> Generator::gen_for() {
   // the loop always declares a fresh variable with a constant start value
   const size_t default_value = rng_.rand(0, cfg_.loop_init_max);
   Instruction init = *gen_var_decl(VariableType::Field(), VariableRole::Local(),
-                                   Expr::Constant(std::to_string(default_value)));
+                                   Expr::Constant((uint64_t)default_value));
   const size_t max = rng_.rand(default_value, cfg_.loop_bound_max);
   const VarRef var_ref = init.var.var_ref;
 
-  Expr cond = Expr::Binary(ExprKind::LessThanEq, Expr::Var(var_ref), Expr::Constant(std::to_string(max)));
+  Expr cond = Expr::Binary(*arena_, ExprKind::LessThanEq, Expr::Var(var_ref), Expr::Constant((uint64_t)max));
   Instruction step =
-      Instruction::Assign(var_ref, Expr::Binary(ExprKind::Add, Expr::Var(var_ref), Expr::Constant("1")));
+      Instruction::Assign(*arena_, var_ref, Expr::Binary(*arena_, ExprKind::Add, Expr::Var(var_ref), Expr::Constant((uint64_t)1)));
 
   std::vector<Instruction> body;
   for (size_t i = 0, n = rng_.rand(1, cfg_.loop_body_max); i < n; i++) push_generated(body, generate_instr());
 
   scope_stack_.leave_scope();
   if (body.empty()) return std::nullopt;  // the loop variable stays in all_vars, the draws are spent
-  return Instruction::For(std::move(init), std::move(cond), std::move(step), std::move(body));
+  return Instruction::For(*arena_, std::move(init), cond, std::move(step), std::move(body));
 }
 
 std::optional<Instruction> Generator::gen_while() {
@@ -344,27 +344,27 @@ std::optional<Instruction> Generator::gen_while() {
   for (size_t i = 0, n = rng_.rand(1, cfg_.loop_body_max); i < n; i++) push_generated(body, generate_instr());
   scope_stack_.leave_scope();
   if (body.empty()) return std::nullopt;
-  return Instruction::While(std::move(*cond), std::move(body));
+  return Instruction::While(*arena_, *cond, std::move(body));
 }
 
 std::optional<Expr> Generator::gen_bin_expr(ExprKind k, size_t depth) {
   std::optional<Expr> left = generate_expr(depth + 1);
   std::optional<Expr> right = generate_expr(depth + 1);
   if (!left || !right) return std::nullopt;
-  return Expr::Binary(k, std::move(*left), std::move(*right));
+  return Expr::Binary(*arena_, k, *left, *right);
 }
 
 std::optional<Expr> Generator::gen_un_expr(ExprKind k, size_t depth) {
   std::optional<Expr> e = generate_expr(depth + 1);
   if (!e) return std::nullopt;
-  return Expr::Unary(k, std::move(*e));
+  return Expr::Unary(*arena_, k, *e);
 }
 
 std::optional<Expr> Generator::generate_expr(size_t depth) {
   // hard limit (generator.rs:486-488)
-  if (depth >= cfg_.max_expr_depth) return Expr::Constant(std::to_string(rng_.next()));
+  if (depth >= cfg_.max_expr_depth) return Expr::Constant(rng_.next());
   // 1/3 chance of stopping early; unreachable at the reference's limit of 1 (generator.rs:490-493)
-  if (depth >= 1 && rng_.rand(1, 3) == 1) return Expr::Constant(std::to_string(rng_.next()));
+  if (depth >= 1 && rng_.rand(1, 3) == 1) return Expr::Constant(rng_.next());
 
   const bool has_field_vars = scope_stack_.ready_fields.count() > 0;    // generator.rs:496-499
   const bool has_array_vars = scope_stack_.touched_arrays.count() > 0;  // generator.rs:502-505
@@ -399,7 +399,7 @@ std::optional<Expr> Generator::gen_var_ref(size_t) {
   return Expr::Var(scope_stack_.flat[scope_stack_.ready_fields.select(rng_.rand(0, n - 1))].var_ref);
 }
 
-std::optional<Expr> Generator::gen_constant(size_t) { return Expr::Constant(std::to_string(rng_.next())); }
+std::optional<Expr> Generator::gen_constant(size_t) { return Expr::Constant(rng_.next()); }
 
 std::optional<Expr> Generator::gen_array_index(size_t) {
   // One draw per array that has a written element, in scope order, then one draw to choose
@@ -420,11 +420,10 @@ std::optional<Expr> Generator::gen_array_index(size_t) {
   chosen_idx = array_draws_[pick] % ((uint64_t)scope_stack_.written_count[chosen_pos] + 1);
   const Variable& v = scope_stack_.flat[chosen_pos];
   if (cfg_.safe_array_index) {  // extension: always a written element
-    size_t written = 0;
-    for (bool b : v.initialized) written += b;
+    const size_t written = v.initialized.count();
     size_t want = chosen_idx % written, seen = 0;
     for (size_t i = 0; i < v.initialized.size(); i++)
-      if (v.initialized[i] && seen++ == want) {
+      if (v.initialized.get(i) && seen++ == want) {
         chosen_idx = i;
         break;
       }
@@ -450,13 +449,13 @@ Expr Generator::gen_linear() {
         k = (k % keep < cfg_.forced_inputs) ? k % keep : sigs.count() - keep + k % keep;
       return Expr::Var(scope_stack_.flat[sigs.select(k)].var_ref);
     }
-    return Expr::Constant(std::to_string(rng_.next()));
+    return Expr::Constant(rng_.next());
   };
   Expr t = term();
   if (cfg_.max_linear_terms == 1) return t;
   const uint64_t shape = rng_.rand(0, 2);
   if (shape == 0) return t;
-  return Expr::Binary(shape == 1 ? ExprKind::Add : ExprKind::Sub, std::move(t), term());
+  return Expr::Binary(*arena_, shape == 1 ? ExprKind::Add : ExprKind::Sub, t, term());
 }
 
 // `fresh output <== lin * lin + lin`: a real rank-1 constraint
@@ -466,8 +465,8 @@ std::optional<Instruction> Generator::gen_constraint_quadratic() {
   const VarRef out = decl->var.var_ref;
   pending_.push_back(std::move(*decl));
   scope_stack_.mark_initialized(out);
-  Expr rhs = Expr::Binary(ExprKind::Add, Expr::Binary(ExprKind::Mul, std::move(a), std::move(b)), std::move(c));
-  return Instruction::Constraint(out, std::move(rhs));
+  Expr rhs = Expr::Binary(*arena_, ExprKind::Add, Expr::Binary(*arena_, ExprKind::Mul, a, b), c);
+  return Instruction::Constraint(*arena_, out, rhs);
 }
 
 }  // namespace zkir

@@ -79,7 +79,7 @@ class Generator {
     void enter_scope() { scope_begin.push_back(flat.size()); }
     void leave_scope();
     bool empty() const { return scope_begin.empty(); }
-    Variable add_var(std::string name, VariableType t, VariableRole r, std::vector<bool> initialized);
+    Variable add_var(std::string name, VariableType t, VariableRole r, InitFlags initialized);
     void mark_initialized(const VarRef& v);
    private:
     void refresh(size_t pos);
@@ -95,6 +95,7 @@ class Generator {
 
   Rng rng_;
   GeneratorConfig cfg_;
+  std::shared_ptr<Arena> arena_ = std::make_shared<Arena>();  // the circuit's expression nodes; handed to the Circuit
   size_t n_instr_ = 0;
   ScopeStack scope_stack_;
   std::vector<Instruction> pending_;  // declarations an extension wants emitted before its statement

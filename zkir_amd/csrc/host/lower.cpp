@@ -313,8 +313,10 @@ class Pass1 {
     } guard{eval_depth_};
     switch (e.kind) {
       case ExprKind::Constant: {
+        if (e.constant.is_u64()) return known_val(U256::from_u64(e.constant.u64()));
         U256 v;
-        if (!fr::parse_decimal(e.constant, &v)) fail(ZKIR_LOWER_BAD_AST, "constant is not a decimal integer: " + e.constant);
+        const std::string text = e.constant.str();
+        if (!fr::parse_decimal(text, &v)) fail(ZKIR_LOWER_BAD_AST, "constant is not a decimal integer: " + text);
         return known_val(v);
       }
       case ExprKind::Var:
@@ -452,25 +454,25 @@ class Pass1 {
       case InstrKind::Constraint: constrain(ins); return;
       case InstrKind::If:
         if (truth(*ins.cond, "if"))
-          exec_block(ins.then_branch);
-        else if (ins.else_branch)
-          exec_block(*ins.else_branch);
+          exec_block(ins.then_branch());
+        else if (ins.else_branch())
+          exec_block(*ins.else_branch());
         return;
       case InstrKind::For: {
-        if (!ins.init || !ins.step || !ins.cond) fail(ZKIR_LOWER_BAD_AST, "malformed for loop");
-        exec(*ins.init);
+        if (!ins.init() || !ins.step() || !ins.cond) fail(ZKIR_LOWER_BAD_AST, "malformed for loop");
+        exec(*ins.init());
         for (;;) {
           if (!truth(*ins.cond, "loop")) break;
           tick();
-          exec_block(ins.body);
-          exec(*ins.step);
+          exec_block(ins.body());
+          exec(*ins.step());
         }
         return;
       }
       case InstrKind::While:
         while (truth(*ins.cond, "loop")) {
           tick();
-          exec_block(ins.body);
+          exec_block(ins.body());
         }
         return;
     }

@@ -48,7 +48,7 @@ std::string NoirTranspiler::transpile_expr(const Expr& e) const {
       return var.name;
     }
     case ExprKind::Constant:
-      return e.constant;
+      return e.constant.str();
     case ExprKind::Equal:
       return "((" + transpile_expr(*e.left) + " == " + transpile_expr(*e.right) + ") as Field)";
     default:
@@ -85,7 +85,7 @@ std::string NoirTranspiler::transpile_instruction(const Instruction& instr) {
       if (!(var.role == VariableRole::Local()) || !var.var_type.is_array)
         throw std::logic_error("ArrayAssign target must be a local array");
       if (instr.index->kind != ExprKind::Constant) throw NoirUnsupported("array index is not a literal");
-      return get_indent() + var.name + "[" + instr.index->constant + "] = " + transpile_expr(*instr.value) + ";";
+      return get_indent() + var.name + "[" + instr.index->constant.str() + "] = " + transpile_expr(*instr.value) + ";";
     }
     case InstrKind::Constraint: {
       const Variable& var = circuit.get_variable(instr.target);
@@ -103,38 +103,38 @@ std::string NoirTranspiler::transpile_instruction(const Instruction& instr) {
     case InstrKind::If: {
       std::string res = get_indent() + "if " + transpile_expr(*instr.cond) + " != 0 {\n";
       indent_size_ += 1;
-      res += transpile_block(instr.then_branch);
+      res += transpile_block(instr.then_branch());
       indent_size_ -= 1;
-      if (instr.else_branch) {
+      if (instr.else_branch()) {
         res += get_indent() + "} else {\n";
         indent_size_ += 1;
-        res += transpile_block(*instr.else_branch);
+        res += transpile_block(*instr.else_branch());
         indent_size_ -= 1;
       }
       return res + get_indent() + "}";
     }
     case InstrKind::For: {
-      if (!instr.init || !instr.step || !instr.cond || instr.init->kind != InstrKind::VarDecl || !instr.init->default_value ||
-          instr.init->default_value->kind != ExprKind::Constant)
+      if (!instr.init() || !instr.step() || !instr.cond || instr.init()->kind != InstrKind::VarDecl || !instr.init()->default_value ||
+          instr.init()->default_value->kind != ExprKind::Constant)
         throw NoirUnsupported("for-loop does not start from a declared constant");
-      const Variable& lv = instr.init->var;
+      const Variable& lv = instr.init()->var;
       const size_t id = lv.var_ref.id;
       const Expr& c = *instr.cond;
       if (c.kind != ExprKind::LessThanEq || !is_var(*c.left, id) || c.right->kind != ExprKind::Constant)
         throw NoirUnsupported("for-loop condition is not `variable <= constant`");
-      const Instruction& st = *instr.step;
+      const Instruction& st = *instr.step();
       if (st.kind != InstrKind::Assign || st.target.id != id || st.value->kind != ExprKind::Add || !is_var(*st.value->left, id) ||
-          st.value->right->kind != ExprKind::Constant || st.value->right->constant != "1")
+          st.value->right->kind != ExprKind::Constant || st.value->right->constant.str() != "1")
         throw NoirUnsupported("for-loop step is not `variable = variable + 1`");
-      if (instr.body.empty()) throw std::logic_error("Empty for loop bodies are not allowed");
+      if (instr.body().empty()) throw std::logic_error("Empty for loop bodies are not allowed");
       // Noir ranges exclude their end and count in an integer type: `lo..(hi + 1)`, with the
       // Field-typed loop variable of the circuit rebuilt from the counter in every trip
-      std::string res = get_indent() + "for " + lv.name + "_i in " + instr.init->default_value->constant + "..(" +
-                        c.right->constant + " + 1) {\n";
+      std::string res = get_indent() + "for " + lv.name + "_i in " + instr.init()->default_value->constant.str() + "..(" +
+                        c.right->constant.str() + " + 1) {\n";
       indent_size_ += 1;
       res += get_indent() + "let " + lv.name + ": Field = " + lv.name + "_i as Field;\n";
       loop_vars_.insert(id);
-      res += transpile_block(instr.body);
+      res += transpile_block(instr.body());
       loop_vars_.erase(id);
       indent_size_ -= 1;
       return res + get_indent() + "}";

@@ -39,7 +39,7 @@ void put_ref(std::string& o, const VarRef& r) {
 
 void put_expr(std::string& o, const Expr& e) {
   switch (e.kind) {
-    case ExprKind::Constant: o += "(const " + quote(e.constant) + ")"; return;
+    case ExprKind::Constant: o += "(const " + quote(e.constant.str()) + ")"; return;
     case ExprKind::Var: o += "(var "; put_ref(o, e.var); o += ")"; return;
     default: break;
   }
@@ -77,16 +77,16 @@ void put_instr(std::string& o, const Instruction& i) {
       o += "(constrain "; put_ref(o, i.target); o += " "; put_expr(o, *i.value); o += ")";
       return;
     case InstrKind::If:
-      o += "(if "; put_expr(o, *i.cond); o += " "; put_block(o, "then", i.then_branch);
-      if (i.else_branch) { o += " "; put_block(o, "else", *i.else_branch); }
+      o += "(if "; put_expr(o, *i.cond); o += " "; put_block(o, "then", i.then_branch());
+      if (i.else_branch()) { o += " "; put_block(o, "else", *i.else_branch()); }
       o += ")";
       return;
     case InstrKind::For:
-      o += "(for "; put_instr(o, *i.init); o += " "; put_expr(o, *i.cond); o += " "; put_instr(o, *i.step);
-      o += " "; put_block(o, "body", i.body); o += ")";
+      o += "(for "; put_instr(o, *i.init()); o += " "; put_expr(o, *i.cond); o += " "; put_instr(o, *i.step());
+      o += " "; put_block(o, "body", i.body()); o += ")";
       return;
     case InstrKind::While:
-      o += "(while "; put_expr(o, *i.cond); o += " "; put_block(o, "body", i.body); o += ")";
+      o += "(while "; put_expr(o, *i.cond); o += " "; put_block(o, "body", i.body()); o += ")";
       return;
   }
 }
@@ -167,11 +167,11 @@ VarRef to_ref(const Node& n) {
   return r;
 }
 
-Expr to_expr(const Node& n) {
+Expr to_expr(Arena& a, const Node& n) {
   const std::string& h = head(n);
   if (h == "const") {
     if (n.items.size() != 2 || !n.items[1].is_string) bad("(const \"decimal\")");
-    return Expr::Constant(n.items[1].atom);
+    return Expr::Constant(Field::from_text(a, n.items[1].atom));
   }
   if (h == "var") {
     if (n.items.size() != 2) bad("(var ref)");
@@ -181,16 +181,17 @@ Expr to_expr(const Node& n) {
     if (h == p.second) {
       if (p.first == ExprKind::BitNot) {
         if (n.items.size() != 2) bad("(bnot expr)");
-        return Expr::Unary(p.first, to_expr(n.items[1]));
+        return Expr::Unary(a, p.first, to_expr(a, n.items[1]));
       }
       if (n.items.size() != 3) bad("(" + h + " expr expr)");
-      return Expr::Binary(p.first, to_expr(n.items[1]), to_expr(n.items[2]));
+      return Expr::Binary(a, p.first, to_expr(a, n.items[1]), to_expr(a, n.items[2]));
     }
   bad("unknown expression " + h);
 }
 
 struct Parser {
   std::map<size_t, Variable> by_id;
+  Arena* arena = nullptr;
   Instruction instr(const Node& n);
   std::vector<Instruction> block(const Node& n, const char* name) {
     if (head(n) != name) bad(std::string("expected (") + name + " ...)");
@@ -208,34 +209,34 @@ Instruction Parser::instr(const Node& n) {
     auto it = by_id.find(to_index(n.items[1]));
     if (it == by_id.end()) bad("decl of an unknown variable id");
     std::optional<Expr> def;
-    if (k == 3) def = to_expr(n.items[2]);
-    return Instruction::VarDecl(it->second, std::move(def));
+    if (k == 3) def = to_expr(*arena, n.items[2]);
+    return Instruction::VarDecl(*arena, it->second, def);
   }
   if (h == "assign") {
     if (k != 3) bad("(assign ref expr)");
-    return Instruction::Assign(to_ref(n.items[1]), to_expr(n.items[2]));
+    return Instruction::Assign(*arena, to_ref(n.items[1]), to_expr(*arena, n.items[2]));
   }
   if (h == "aassign") {
     if (k != 4) bad("(aassign ref index expr)");
-    return Instruction::ArrayAssign(to_ref(n.items[1]), to_expr(n.items[2]), to_expr(n.items[3]));
+    return Instruction::ArrayAssign(*arena, to_ref(n.items[1]), to_expr(*arena, n.items[2]), to_expr(*arena, n.items[3]));
   }
   if (h == "constrain") {
     if (k != 3) bad("(constrain ref expr)");
-    return Instruction::Constraint(to_ref(n.items[1]), to_expr(n.items[2]));
+    return Instruction::Constraint(*arena, to_ref(n.items[1]), to_expr(*arena, n.items[2]));
   }
   if (h == "if") {
     if (k != 3 && k != 4) bad("(if cond (then ...) [(else ...)])");
     std::optional<std::vector<Instruction>> el;
     if (k == 4) el = block(n.items[3], "else");
-    return Instruction::If(to_expr(n.items[1]), block(n.items[2], "then"), std::move(el));
+    return Instruction::If(*arena, to_expr(*arena, n.items[1]), block(n.items[2], "then"), std::move(el));
   }
   if (h == "for") {
     if (k != 5) bad("(for init cond step (body ...))");
-    return Instruction::For(instr(n.items[1]), to_expr(n.items[2]), instr(n.items[3]), block(n.items[4], "body"));
+    return Instruction::For(*arena, instr(n.items[1]), to_expr(*arena, n.items[2]), instr(n.items[3]), block(n.items[4], "body"));
   }
   if (h == "while") {
     if (k != 3) bad("(while cond (body ...))");
-    return Instruction::While(to_expr(n.items[1]), block(n.items[2], "body"));
+    return Instruction::While(*arena, to_expr(*arena, n.items[1]), block(n.items[2], "body"));
   }
   bad("unknown instruction " + h);
 }
@@ -269,6 +270,7 @@ Circuit parse_circuit(const std::string& text) {
   if (head(vars) != "vars" || head(instrs) != "instrs") bad("expected (vars ...) then (instrs ...)");
   Parser ps;
   Circuit c;
+  ps.arena = c.arena.get();
   for (size_t i = 1; i < vars.items.size(); i++) {
     const Node& n = vars.items[i];
     if (head(n) != "var" || n.items.size() != 6) bad("(var id \"name\" type role (init ...))");
