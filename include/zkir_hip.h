@@ -295,6 +295,16 @@ int32_t zkir_lower_options_default(zkir_lower_options* o);
  * ZKIR_LOWER_*; opts may be NULL (defaults). */
 int32_t zkir_lower(const zkir_circuit* c, const zkir_lower_options* opts, zkir_tape** out, int32_t* status_class);
 
+/* The host side of a campaign in one call (no counterpart in the reference, whose main() makes one
+ * circuit: src/main.rs:81-92): for k in 0..n, zkir_generate(seeds[k], &cfgs[k]) then zkir_lower(., opts),
+ * spread over `threads` host threads.  tapes[k] receives the tape, or NULL with status_classes[k] set to the
+ * ZKIR_LOWER_* class that refused the circuit (that is a result: the call still returns ZKIR_OK).  cfgs may
+ * be NULL (defaults for every circuit), opts may be NULL.  On any other error every tape made so far is
+ * freed and the code is returned.  The caller frees the tapes with zkir_tape_free. */
+int32_t zkir_generate_lower_many(const uint64_t* seeds, const zkir_generator_config* cfgs, uint32_t n,
+                                 const zkir_lower_options* opts, uint32_t threads, zkir_tape** tapes,
+                                 int32_t* status_classes);
+
 int32_t zkir_tape_header(const zkir_tape* t, zkir_tape_hdr* hdr);
 int32_t zkir_tape_blob(const zkir_tape* t, const void** blob, size_t* bytes);
 /* Where each signal variable sits in an input (which = 0) or output (which = 1)

@@ -78,3 +78,41 @@ def test_two_gloo_ranks_equal_one_rank(tmp_path):
         assert o == single  # every rank holds the job-wide totals and the union of divergent ids
     assert single["unsat"] == 3 * len(single["divergent"]) and len(single["divergent"]) >= 2
     assert single["rejected"] == sum(single["classes"][1:]) and sum(single["classes"]) == N_CIRCUITS
+
+
+def test_batched_generate_and_lower_equals_one_by_one():
+    """zkir_generate_lower_many on several threads gives, circuit for circuit, the tape (or the refusal)
+    that zkir_generate + zkir_lower give, and lower_parallel hands them out in id order."""
+    o = z.default_lower_options()
+    o.max_iterations = 200
+    ids = list(range(40))
+    expect = []
+    for cid in ids:
+        c = z.Generator(campaign.circuit_seed(BASE_SEED, cid), small_config(cid)).generate()
+        try:
+            t = z.Lowerer(c, o).lower()
+            expect.append((0, bytes(t.hdr), t.blob(), t.io_map(0), t.io_map(1)))
+        except z.LowerRejected as e:
+            expect.append((e.status_class, None, None, None, None))
+    assert any(cls for cls, *_ in expect) and any(cls == 0 for cls, *_ in expect)
+    for threads in (1, 3, 64):
+        got = z.generate_lower_many([campaign.circuit_seed(BASE_SEED, c) for c in ids], [small_config(c) for c in ids], o, threads)
+        assert [(cls, bytes(t.hdr) if t else None, t.blob() if t else None, t.io_map(0) if t else None,
+                 t.io_map(1) if t else None) for cls, t in got] == expect
+    out = list(campaign.lower_parallel(ids, BASE_SEED, workers=2, window=3, lower_options=o, config_of=small_config))
+    assert [cid for cid, _, _ in out] == ids
+    assert [(cls, t.blob() if t else None) for _, cls, t in out] == [(e[0], e[2]) for e in expect]
+    assert z.generate_lower_many([], None, None, 4) == []
+    # a bad generator config fails the whole call with the library's error, not a crash or a partial list
+    bad = small_config(1)
+    bad.min_instructions, bad.max_instructions = 9, 3
+    try:
+        z.generate_lower_many([5, 6, 7], [small_config(0), bad, small_config(2)], o, 2)
+        assert False, "expected an error"
+    except z.ZkirError as e:
+        assert e.code == z.E_INVALID
+    try:
+        z.generate_lower_many([5, 0], None, o, 2)  # seed 0 is rejected like zkir_generate rejects it
+        assert False, "expected an error"
+    except z.ZkirError as e:
+        assert e.code == z.E_INVALID

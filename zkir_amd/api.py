@@ -79,6 +79,8 @@ def _load():
         "zkir_gadget_poseidon_style": [c_uint32, c_uint32, c_uint64, P(c_void_p)],
         "zkir_lower_options_default": [P(LowerOptions)],
         "zkir_lower": [c_void_p, P(LowerOptions), P(c_void_p), P(c_int32)],
+        "zkir_generate_lower_many": [P(c_uint64), P(GeneratorConfig), c_uint32, P(LowerOptions), c_uint32, P(c_void_p),
+                                     P(c_int32)],
         "zkir_tape_header": [c_void_p, P(TapeHdr)],
         "zkir_tape_blob": [c_void_p, P(c_void_p), P(c_size_t)],
         "zkir_tape_io_map": [c_void_p, c_int32, P(c_uint64), c_size_t, P(c_size_t)],
@@ -281,6 +283,22 @@ class Lowerer:
             raise LowerRejected(cls.value, lib.zkir_host_last_error().decode())
         _host_check(rc)
         return Tape(h)
+
+
+def generate_lower_many(seeds, configs=None, options=None, threads=1):
+    """zkir_generate_lower_many: circuit k from (seeds[k], configs[k]) generated and lowered on `threads` host
+    threads inside the library.  Returns [(status class, Tape or None)]."""
+    n = len(seeds)
+    if n == 0:
+        return []
+    if configs is not None and len(configs) != n:
+        raise ValueError("one generator config per seed")
+    c_seeds = (c_uint64 * n)(*seeds)
+    c_cfgs = (GeneratorConfig * n)(*configs) if configs is not None else None
+    tapes, classes = (c_void_p * n)(), (c_int32 * n)()
+    _host_check(lib.zkir_generate_lower_many(c_seeds, c_cfgs, n, byref(options) if options is not None else None,
+                                             threads, tapes, classes))
+    return [(classes[k], Tape(c_void_p(tapes[k])) if tapes[k] else None) for k in range(n)]
 
 
 def pack_inputs(vectors, n_inputs):

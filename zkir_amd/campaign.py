@@ -39,34 +39,40 @@ def campaign_config(circuit_id, min_constraints=64, max_constraints=4096):
     return g
 
 
-def _lower_one(args):
-    cid, base_seed, lower_options = args
-    try:
-        circuit = api.Generator(circuit_seed(base_seed, cid), campaign_config(cid)).generate()
-        return cid, 0, api.Lowerer(circuit, lower_options).lower()
-    except api.LowerRejected as e:
-        return cid, e.status_class, None
-
-
-def lower_parallel(circuit_ids, base_seed, workers=8, window=64, lower_options=None):
+def lower_parallel(circuit_ids, base_seed, workers=8, window=64, lower_options=None, config_of=campaign_config):
     """Generate and lower campaign circuits on `workers` host threads; yields
-    (circuit id, class, Tape or None) in id order.  The library's host functions keep no
-    shared state and ctypes drops the interpreter lock around them, so plain threads scale
-    (and nothing is forked from a process that may already hold a GPU context).  At most
-    `window` x workers circuits are in flight ahead of the consumer."""
-    from collections import deque
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(workers) as ex:
-        pending, it = deque(), iter(circuit_ids)
-        for cid in it:
-            pending.append(ex.submit(_lower_one, (cid, base_seed, lower_options)))
-            if len(pending) >= window * workers:
-                break
-        while pending:
-            yield pending.popleft().result()
-            for cid in it:
-                pending.append(ex.submit(_lower_one, (cid, base_seed, lower_options)))
-                break
+    (circuit id, class, Tape or None) in id order.  The circuits go to the library `window` x workers
+    at a time (zkir_generate_lower_many: the threads are the library's own and nothing passes through
+    Python per circuit); one helper thread keeps the next batch in the making while the consumer works
+    on the last one (ctypes drops the interpreter lock for the call, and nothing is forked from a process
+    that may already hold a GPU context)."""
+    import queue
+    import threading
+    ids = list(circuit_ids)
+    step = max(1, window * workers)
+    batches = queue.Queue(maxsize=2)
+
+    def produce():
+        try:
+            for at in range(0, len(ids), step):
+                part = ids[at:at + step]
+                made = api.generate_lower_many([circuit_seed(base_seed, c) for c in part], [config_of(c) for c in part],
+                                               lower_options, workers)
+                batches.put((part, made))
+            batches.put(None)
+        except BaseException as e:  # hand the failure to the consumer instead of leaving it waiting
+            batches.put(e)
+
+    threading.Thread(target=produce, daemon=True).start()
+    while True:
+        item = batches.get()
+        if item is None:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        part, made = item
+        for cid, (cls, tape) in zip(part, made):
+            yield cid, cls, tape
 
 
 class LocalResult:

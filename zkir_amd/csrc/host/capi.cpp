@@ -1,8 +1,13 @@
 // The host half of include/zkir_hip.h: the reference-side mirror (generate, print,
 // transpile) and lower, behind a C boundary that never lets an exception through.
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../../include/zkir_hip.h"
 #include "../hip/tape_check.h"
@@ -192,6 +197,63 @@ int32_t zkir_lower(const zkir_circuit* c, const zkir_lower_options* opts, zkir_t
     g_host_error = "unknown exception";
     return ZKIR_E_INTERNAL;
   }
+}
+
+// A campaign's inner loop on the host: circuit k is what zkir_generate(seeds[k], &cfgs[k]) followed by
+// zkir_lower(., opts) would give, done on `threads` host threads with nothing crossing the boundary per
+// circuit.  tapes[k] is the tape (status_classes[k] == ZKIR_LOWER_OK) or NULL with the class that refused it.
+int32_t zkir_generate_lower_many(const uint64_t* seeds, const zkir_generator_config* cfgs, uint32_t n,
+                                 const zkir_lower_options* opts, uint32_t threads, zkir_tape** tapes,
+                                 int32_t* status_classes) {
+  if (n && (!seeds || !tapes || !status_classes)) return ZKIR_E_INVALID;
+  for (uint32_t k = 0; k < n; k++) {
+    tapes[k] = nullptr;
+    status_classes[k] = ZKIR_LOWER_OK;
+  }
+  const zkir::LowerOptions o = opts ? *opts : zkir::default_lower_options();
+  std::atomic<uint32_t> next{0};
+  std::atomic<int32_t> failed{ZKIR_OK};
+  std::mutex error_lock;
+  std::string first_error;
+  auto work = [&]() {
+    for (;;) {
+      const uint32_t k = next.fetch_add(1);
+      if (k >= n || failed.load() != ZKIR_OK) return;
+      zkir_circuit* c = nullptr;
+      int32_t rc = zkir_generate(seeds[k], cfgs ? &cfgs[k] : nullptr, &c);
+      if (rc == ZKIR_OK) {
+        rc = zkir_lower(c, &o, &tapes[k], &status_classes[k]);
+        if (rc == ZKIR_E_LOWER) rc = ZKIR_OK;  // a refused circuit is a result, not a failure of the call
+      }
+      zkir_circuit_free(c);
+      if (rc != ZKIR_OK) {
+        std::lock_guard<std::mutex> g(error_lock);
+        if (failed.load() == ZKIR_OK) {
+          failed.store(rc);
+          first_error = "circuit " + std::to_string(k) + ": " + g_host_error;  // this worker's own message
+        }
+        return;
+      }
+    }
+  };
+  try {
+    const uint32_t n_threads = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(threads ? threads : 1, n), 256));
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < n_threads; t++) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+  } catch (const std::exception& e) {
+    failed.store(ZKIR_E_INTERNAL);
+    first_error = e.what();
+  }
+  if (failed.load() != ZKIR_OK) {
+    for (uint32_t k = 0; k < n; k++) {
+      zkir_tape_free(tapes[k]);
+      tapes[k] = nullptr;
+    }
+    g_host_error = first_error;
+  }
+  return failed.load();
 }
 
 int32_t zkir_tape_header(const zkir_tape* t, zkir_tape_hdr* hdr) {

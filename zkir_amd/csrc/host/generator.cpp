@@ -140,7 +140,9 @@ Circuit Generator::generate() {
 
   const size_t n = rng_.rand(cfg_.min_instructions, cfg_.max_instructions);
   requested_ = n;
-  instructions.reserve(n + n / 2 + cfg_.forced_inputs);  // an Instruction is costly to move
+  instructions.reserve(n + n / 2 + cfg_.forced_inputs);
+  scope_stack_.flat.reserve(n / 2 + cfg_.forced_inputs + 16);
+  scope_stack_.all_vars.reserve(n / 2 + cfg_.forced_inputs + 16);
 
   // extension: scalar input signals declared before anything else
   for (uint32_t k = 0; k < cfg_.forced_inputs; k++) {

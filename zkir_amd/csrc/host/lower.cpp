@@ -67,8 +67,8 @@ struct Val {
 };
 
 struct Cells {
-  Variable var;
-  std::vector<Val> cell;
+  const Variable* var = nullptr;  // in circuit.variables
+  size_t off = 0, len = 0;  // its elements are vals_[off .. off+len) once it has been declared
   size_t io_offset = 0;  // signals: first element in the input / output vector
   int declared = 0;      // times the declaration has executed
 };
@@ -92,10 +92,10 @@ class Pass1 {
 
   void run() {
     // signal layout: declaration order in circuit.variables, arrays flattened
+    cells_.reserve(circuit_.variables.size());
     for (const Variable& v : circuit_.variables) {
-      if (vars_.count(v.var_ref.id)) fail(ZKIR_LOWER_BAD_AST, "duplicate variable id");
       Cells c;
-      c.var = v;
+      c.var = &v;
       const size_t len = v.var_type.is_array ? v.var_type.len : 1;
       if (v.role.is_input()) {
         c.io_offset = n_inputs;
@@ -106,8 +106,23 @@ class Pass1 {
         outputs.push_back({v.var_ref.id, n_outputs, len});
         n_outputs += len;
       }
-      vars_[v.var_ref.id] = std::move(c);
+      cells_.push_back(std::move(c));
     }
+    // id -> position in cells_: a table when the ids are dense (the generator numbers them 0, 1, 2, ...), else a map
+    size_t max_id = 0;
+    for (const Variable& v : circuit_.variables) max_id = std::max(max_id, v.var_ref.id);
+    const bool dense = max_id < 4 * cells_.size() + 1024;
+    if (dense) pos_of_id_.assign(max_id + 1, -1);
+    for (size_t k = 0; k < cells_.size(); k++) {
+      const size_t id = cells_[k].var->var_ref.id;
+      if (dense) {
+        if (pos_of_id_[id] >= 0) fail(ZKIR_LOWER_BAD_AST, "duplicate variable id");
+        pos_of_id_[id] = (int32_t)k;
+      } else if (!pos_of_sparse_id_.emplace(id, (uint32_t)k).second) {
+        fail(ZKIR_LOWER_BAD_AST, "duplicate variable id");
+      }
+    }
+    dense_ids_ = dense;
     output_written_.assign(n_outputs, false);
     exec_block(circuit_.instructions);
     // every output element is defined: the ones nothing constrained read as 0
@@ -149,25 +164,29 @@ class Pass1 {
   }
 
   Cells& cells_of(const VarRef& r) {
-    auto it = vars_.find(r.id);
-    if (it == vars_.end()) fail(ZKIR_LOWER_BAD_AST, "variable " + std::to_string(r.id) + " not found");
-    return it->second;
+    if (dense_ids_) {
+      if (r.id < pos_of_id_.size() && pos_of_id_[r.id] >= 0) return cells_[(size_t)pos_of_id_[r.id]];
+    } else {
+      auto it = pos_of_sparse_id_.find(r.id);
+      if (it != pos_of_sparse_id_.end()) return cells_[it->second];
+    }
+    fail(ZKIR_LOWER_BAD_AST, "variable " + std::to_string(r.id) + " not found");
   }
 
   Val read_var(const VarRef& r) {
     Cells& c = cells_of(r);
-    if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "variable " + c.var.name + " used before its declaration");
+    if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "variable " + c.var->name + " used before its declaration");
     size_t k = 0;
-    if (c.var.var_type.is_array) {
-      if (!r.idx) fail(ZKIR_LOWER_BAD_AST, "array " + c.var.name + " referenced without an index");
-      if (*r.idx >= c.cell.size()) fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var.name);
+    if (c.var->var_type.is_array) {
+      if (!r.idx) fail(ZKIR_LOWER_BAD_AST, "array " + c.var->name + " referenced without an index");
+      if (*r.idx >= c.len) fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var->name);
       k = *r.idx;
     } else if (r.idx) {
-      fail(ZKIR_LOWER_BAD_AST, "index on the scalar " + c.var.name);
+      fail(ZKIR_LOWER_BAD_AST, "index on the scalar " + c.var->name);
     }
-    Val& v = c.cell[k];
-    if (!v.assigned) fail(ZKIR_LOWER_UNINIT_SIGNAL, "signal " + c.var.name + " read before it is assigned");
-    if (c.var.role.is_input() && v.ref == kNoRef) {
+    Val& v = vals_[c.off + k];
+    if (!v.assigned) fail(ZKIR_LOWER_UNINIT_SIGNAL, "signal " + c.var->name + " read before it is assigned");
+    if (c.var->role.is_input() && v.ref == kNoRef) {
       // first read of this input element: load it (and convert it) once
       const Ref x = n_values++;
       emit({ZKIR_OP_INPUT, x, (Ref)(c.io_offset + k), kNoRef});
@@ -350,42 +369,50 @@ class Pass1 {
   // ---- statements ----
   void declare(const Instruction& ins) {
     Cells& c = cells_of(ins.var.var_ref);
-    const size_t len = c.var.var_type.is_array ? c.var.var_type.len : 1;
-    if (c.var.role.is_signal && c.declared) fail(ZKIR_LOWER_DOUBLE_ASSIGN, "signal " + c.var.name + " declared again by a loop");
+    const size_t len = c.var->var_type.is_array ? c.var->var_type.len : 1;
+    if (c.var->role.is_signal && c.declared) fail(ZKIR_LOWER_DOUBLE_ASSIGN, "signal " + c.var->name + " declared again by a loop");
     c.declared++;
-    c.cell.assign(len, Val());
-    if (c.var.role.is_local()) {
-      for (Val& v : c.cell) v = known_val(U256());  // circom variables start at 0
-    } else if (c.var.role.is_input()) {
-      for (Val& v : c.cell) {
-        v.assigned = true;
-        v.deg = kLinear;
-        v.from_signal = true;
+    if (c.len != len) {  // first execution of the declaration: its elements go at the end of vals_
+      c.off = vals_.size();
+      c.len = len;
+      vals_.resize(vals_.size() + len);
+    }
+    Val* cell = vals_.data() + c.off;
+    for (size_t k = 0; k < len; k++) cell[k] = Val();
+    if (c.var->role.is_local()) {
+      for (size_t k = 0; k < len; k++) cell[k] = known_val(U256());  // circom variables start at 0
+    } else if (c.var->role.is_input()) {
+      for (size_t k = 0; k < len; k++) {
+        cell[k].assigned = true;
+        cell[k].deg = kLinear;
+        cell[k].from_signal = true;
       }
     }
     if (ins.default_value) {
-      if (!c.var.role.is_local() || c.var.var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "default value on " + c.var.name);
-      c.cell[0] = eval(*ins.default_value);
+      if (!c.var->role.is_local() || c.var->var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "default value on " + c.var->name);
+      Val d = eval(*ins.default_value);
+      vals_[c.off] = std::move(d);
     }
   }
 
   void assign(const Instruction& ins) {
     Cells& c = cells_of(ins.target);
-    if (!c.var.role.is_local() || c.var.var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "Assign target must be a local field");
+    if (!c.var->role.is_local() || c.var->var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "Assign target must be a local field");
     if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "assignment before declaration");
-    c.cell[0] = eval(*ins.value);
+    Val v = eval(*ins.value);
+    vals_[c.off] = std::move(v);
   }
 
   void array_assign(const Instruction& ins) {
     Cells& c = cells_of(ins.target);
-    if (!c.var.role.is_local() || !c.var.var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "ArrayAssign target must be a local array");
+    if (!c.var->role.is_local() || !c.var->var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "ArrayAssign target must be a local array");
     if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "assignment before declaration");
     Val idx = eval(*ins.index);
     if (!idx.known || idx.from_signal) fail(ZKIR_LOWER_UNKNOWN_CONTROL, "array index depends on a signal");
-    if (idx.value.w[1] | idx.value.w[2] | idx.value.w[3] || idx.value.w[0] >= c.cell.size())
-      fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var.name);
+    if (idx.value.w[1] | idx.value.w[2] | idx.value.w[3] || idx.value.w[0] >= c.len)
+      fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var->name);
     Val v = eval(*ins.value);
-    cells_of(ins.target).cell[(size_t)idx.value.w[0]] = std::move(v);
+    vals_[c.off + (size_t)idx.value.w[0]] = std::move(v);
   }
 
   // sum(coef * ref) as one tape value; kNoRef when there are no terms
@@ -403,17 +430,17 @@ class Pass1 {
 
   void constrain(const Instruction& ins) {
     Cells& c = cells_of(ins.target);
-    if (!c.var.role.is_output()) fail(ZKIR_LOWER_BAD_AST, "Constraint target must be an output signal");
+    if (!c.var->role.is_output()) fail(ZKIR_LOWER_BAD_AST, "Constraint target must be an output signal");
     if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "constraint before declaration");
     size_t k = 0;
-    if (c.var.var_type.is_array) {
+    if (c.var->var_type.is_array) {
       if (!ins.target.idx) fail(ZKIR_LOWER_BAD_AST, "array signal constrained without an index");
-      if (*ins.target.idx >= c.cell.size()) fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var.name);
+      if (*ins.target.idx >= c.len) fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var->name);
       k = *ins.target.idx;
     }
-    if (c.cell[k].assigned) fail(ZKIR_LOWER_DOUBLE_ASSIGN, "signal " + c.var.name + " assigned twice");
+    if (vals_[c.off + k].assigned) fail(ZKIR_LOWER_DOUBLE_ASSIGN, "signal " + c.var->name + " assigned twice");
     Val v = eval(*ins.value);
-    if (v.deg == kNonQuadratic) fail(ZKIR_LOWER_NON_QUADRATIC, "non quadratic constraint on " + c.var.name);
+    if (v.deg == kNonQuadratic) fail(ZKIR_LOWER_NON_QUADRATIC, "non quadratic constraint on " + c.var->name);
     // `<==` is `<--` followed by `===`: the signal takes the value, then A*B == C is checked
     const Ref out = ref_of(v);
     const size_t out_index = cells_of(ins.target).io_offset + k;
@@ -437,7 +464,7 @@ class Pass1 {
     sig.value = v.value;
     sig.ref = out;
     sig.deg = v.known ? kKnown : kLinear;
-    cells_of(ins.target).cell[k] = std::move(sig);
+    vals_[c.off + k] = std::move(sig);
   }
 
   bool truth(const Expr& cond, const char* what) {
@@ -492,7 +519,11 @@ class Pass1 {
   LowerOptions opts_;
   size_t max_ops_;
   uint64_t max_iterations_;
-  std::unordered_map<size_t, Cells> vars_;
+  std::vector<Cells> cells_;  // one per circuit variable, in declaration order
+  std::vector<Val> vals_;     // the elements of every declared variable
+  std::vector<int32_t> pos_of_id_;
+  std::unordered_map<size_t, uint32_t> pos_of_sparse_id_;
+  bool dense_ids_ = true;
   std::unordered_map<U256, uint32_t, U256Hash> const_ids_;
   std::vector<bool> output_written_;
   uint64_t iterations_ = 0;
@@ -548,7 +579,7 @@ StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>&
   std::vector<uint32_t> free_l, free_g;
   for (uint32_t k = opts.n_lslots; k-- > 0;) free_l.push_back(k);
   // values whose slot is released after op i
-  std::vector<std::vector<int32_t>> dies_at(n);
+  std::vector<int32_t> dies_head(n, -1), dies_next(nv, -1);  // per op: list of the values whose last read it is
   const int64_t kWindowLifetime = opts.window_lifetime ? opts.window_lifetime : 48;
 
   StreamOut out;
@@ -625,13 +656,16 @@ StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>&
           home[v].operand = ZKIR_OPERAND(ZKIR_KIND_GSLOT, s);
         }
         t.dst = home[v].operand;
-        if (opts.reuse_slots) dies_at[(size_t)last_use[v]].push_back(v);
+        if (opts.reuse_slots) {
+          dies_next[v] = dies_head[(size_t)last_use[v]];
+          dies_head[(size_t)last_use[v]] = v;
+        }
       }
     }
     out.ops[i] = t;
     // release the slots of values read for the last time by this op; a slot freed here can
     // be the destination of a LATER op only, never of this one (its store is already placed)
-    for (int32_t v : dies_at[i]) {
+    for (int32_t v = dies_head[i]; v >= 0; v = dies_next[v]) {
       const uint32_t kind = home[v].operand >> ZKIR_KIND_SHIFT, idx = home[v].operand & ZKIR_INDEX_MASK;
       if (kind == ZKIR_KIND_LSLOT) free_l.push_back(idx);
       if (kind == ZKIR_KIND_GSLOT) free_g.push_back(idx);

@@ -32,7 +32,9 @@ class Rng {
   uint64_t rand(uint64_t min, uint64_t max) {
     if (min > max) throw std::logic_error("Invalid range");
     if (min == max) return min;
-    return min + next() % (max - min + 1);
+    const uint64_t n = max - min + 1;
+    if ((n & (n - 1)) == 0 && n) return min + (next() & (n - 1));  // same value as the remainder, without the division
+    return min + next() % n;
   }
 
   // rng.rs:36-45
