@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="split the 2^log2-vectors batch over the ranks (contiguous ranges) instead of giving every "
                          "rank a batch of that size: the fixed-size reading of configs 2 and 5")
-    ap.add_argument("--strands", default="auto", choices=["auto", "0", "4"],
+    ap.add_argument("--strands", default="auto", choices=["auto", "0", "4", "8"],
                     help="gadget only: lower into a strand tape (4, and auto) or a plain tape (0)")
     ap.add_argument("--signal-window", type=int, default=0,
                     help="config2 only: linear terms read the inputs and the last W signals instead of any "

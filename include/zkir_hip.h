@@ -62,9 +62,10 @@ extern "C" {
  *     uint32_t  triples[n_constraints][3]  operands (a, b, c): w[a]*w[b]==w[c]
  *
  * Strand tapes (flags & ZKIR_TAPE_F_STRANDS).  A circuit whose ops are not one
- * dependent chain can be cut into ZKIR_STRANDS op streams that run side by side, one
+ * dependent chain can be cut into n_strands (4 or 8) op streams that run side by side, one
  * wavefront each, on the SAME 64 input vectors (instead of four wavefronts on 256
- * vectors): the shape for batches too small to fill the machine.  ops[] then holds
+ * vectors): the shape for batches too small to fill the machine; the smaller the batch,
+ * the more strands pay.  ops[] then holds
  * strand 0's ops, then strand 1's, ... (strand_ops[] each).  Every strand has its own
  * accumulator and its own GSLOT / LSLOT slots; values cross between strands only through
  * XSLOT operands, and only across a ZKIR_OP_BARRIER: a strand may read an exchange slot
@@ -74,10 +75,11 @@ extern "C" {
  * (bits 8..31 of `code` = constraint number + 1), since a strand sees only its own checks.
  */
 #define ZKIR_TAPE_F_STRANDS 1u
-#define ZKIR_STRANDS 4u
-#define ZKIR_MAX_XSLOTS 32u
+#define ZKIR_STRANDS 4u     /* strands of a strand tape: this many ... */
+#define ZKIR_MAX_STRANDS 8u /* ... or this many (zkir_tape_hdr.n_strands) */
+#define ZKIR_MAX_XSLOTS 48u
 #define ZKIR_TAPE_MAGIC 0x31544b5au /* "ZKT1" */
-#define ZKIR_TAPE_VERSION 1u
+#define ZKIR_TAPE_VERSION 2u
 
 typedef struct zkir_op {
   uint32_t code; /* zkir_opcode in bits 0..7; bits 8..31: 0, or in a strand
@@ -155,9 +157,11 @@ typedef struct zkir_tape_hdr {
   uint32_t n_constraints; /* number of ZKIR_OP_CHECK ops                        */
   uint32_t n_mul_ops;     /* ZKIR_OP_MUL ops (work accounting only)             */
   uint32_t flags;         /* ZKIR_TAPE_F_*                                      */
-  uint32_t strand_ops[4]; /* strand tapes: ops of each strand (sum = n_ops); else 0 */
+  uint32_t strand_ops[8]; /* strand tapes: ops of each strand (sum = n_ops); else 0 */
   uint32_t n_xslots;      /* strand tapes: exchange slots (<= ZKIR_MAX_XSLOTS)  */
-} zkir_tape_hdr; /* 64 bytes; n_gslots / n_lslots of a strand tape are per strand */
+  uint32_t n_strands;     /* strand tapes: ZKIR_STRANDS or ZKIR_MAX_STRANDS; else 0 */
+  uint32_t reserved;      /* 0 */
+} zkir_tape_hdr; /* 88 bytes; n_gslots / n_lslots of a strand tape are per strand */
 
 #define ZKIR_MAX_LSLOTS 16u
 
@@ -282,11 +286,13 @@ typedef struct zkir_lower_options {
   uint32_t window_lifetime;/* values read for the last time more than this many
                               ops after their definition go to device memory,
                               not the on-chip window (0 = 48)                 */
-  uint32_t strands;        /* 4: cut the ops into four strands (a strand tape, for
-                              batches too small to fill the machine) when the
-                              circuit is made of + - * and its cross-strand values
-                              fit the exchange slots; 0: one op stream          */
-  uint32_t max_xslots;     /* exchange slots a strand tape may use (0 = 32)     */
+  uint32_t strands;        /* 4 or 8: cut the ops into that many strands (a strand
+                              tape, for batches too small to fill the machine:
+                              8 for the smallest) when the circuit is made of
+                              + - * and its cross-strand values fit the exchange
+                              slots; 0: one op stream                           */
+  uint32_t max_xslots;     /* exchange slots a strand tape may use (0 = 32, or
+                              ZKIR_MAX_XSLOTS with 8 strands)                   */
 } zkir_lower_options;
 
 int32_t zkir_lower_options_default(zkir_lower_options* o);

@@ -27,10 +27,10 @@ typedef struct { uint64_t w[4]; } fe;
 typedef struct { uint32_t code, dst, a, b; } op_t;
 typedef struct {
   uint32_t magic, version, n_inputs, n_outputs, n_consts, n_ops, n_gslots, n_lslots, n_constraints, n_mul_ops, flags,
-      strand_ops[4], n_xslots;
+      strand_ops[8], n_xslots, n_strands, reserved;
 } hdr_t;
 enum { K_GSLOT = 0, K_LSLOT = 1, K_CONST = 2, K_INPUT = 3, K_ACC = 4, K_NONE = 5, K_XSLOT = 6 };
-enum { F_STRANDS = 1, STRANDS = 4 };
+enum { F_STRANDS = 1, STRANDS = 8 };  /* STRANDS: the most a tape can have (n_strands is 4 or 8) */
 enum {
   OP_NOP = 0, OP_INPUT = 1, OP_OUTPUT = 2, OP_COPY = 3, OP_NEG = 4, OP_BNOT = 5, OP_BNOT256 = 6, OP_BARRIER = 7,
   OP_ADD = 16, OP_SUB, OP_MUL, OP_POW, OP_DIV, OP_IDIV, OP_REM, OP_LT, OP_LE, OP_GT, OP_GE, OP_EQ, OP_AND, OP_OR,
@@ -218,7 +218,7 @@ static void store_soa(uint32_t* base, uint64_t N, uint64_t elem, uint64_t t, con
 static void* run_range(void* arg) {
   job_t* j = (job_t*)arg;
   const hdr_t* h = j->h;
-  const int strands = (h->flags & F_STRANDS) ? STRANDS : 1;
+  const int strands = (h->flags & F_STRANDS) ? (int)h->n_strands : 1;
   fe* gbuf = (fe*)malloc(sizeof(fe) * ((size_t)h->n_gslots + 1) * (size_t)strands);
   fe lbuf[STRANDS][16], accs[STRANDS], x[64], one = {{1, 0, 0, 0}};
   uint32_t begin[STRANDS + 1];
@@ -290,6 +290,7 @@ int zkir_eval_cpu(const void* hdr, const void* blob, const uint32_t* inputs_soa,
                   uint64_t* unsat_count, uint32_t* first_unsat, uint64_t* faults, int n_threads) {
   const hdr_t* h = (const hdr_t*)hdr;
   if (!h || h->n_lslots > 16 || h->n_xslots > 64 || n_threads < 1 || n_threads > 1024) return -1;
+  if ((h->flags & F_STRANDS) && h->n_strands != 4 && h->n_strands != 8) return -1;
   const op_t* ops = (const op_t*)blob;
   const uint32_t* craw = (const uint32_t*)((const char*)blob + (size_t)h->n_ops * 16);
   fe* cm = (fe*)malloc(sizeof(fe) * (h->n_consts + 1));

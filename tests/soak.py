@@ -36,7 +36,7 @@ for it in range(N):
     o.fold_constants = rnd.choice([0, 1])
     o.bnot_variant = rnd.choice([0, 1])
     o.max_iterations = 300
-    o.strands = rnd.choice([0, 0, 4])  # strand tapes where the circuit allows (+ - * only, few crossing values)
+    o.strands = rnd.choice([0, 0, 4, 8])  # strand tapes where the circuit allows (+ - * only, few crossing values)
     o.max_xslots = rnd.choice([0, 0, 6, 16])
     seed = rnd.randrange(1, 1 << 62)
     try:

@@ -48,7 +48,7 @@ def interpreter_kernel(request):
 
 def hand_tape(ops, consts, n_inputs, n_outputs, n_g, n_l):
     n_con = sum(1 for o in ops if o[0] == F.OP_CHECK)
-    hdr = api.TapeHdr(0x31544B5A, 1, n_inputs, n_outputs, len(consts), len(ops), n_g, n_l, n_con, 0, 0)
+    hdr = api.TapeHdr(0x31544B5A, 2, n_inputs, n_outputs, len(consts), len(ops), n_g, n_l, n_con, 0, 0)
     blob = b"".join(struct.pack("<4I", *o) for o in ops) + b"".join(struct.pack("<8I", *F.limbs32(c)) for c in consts)
     blob += b"".join(struct.pack("<3I", o[2], o[3], o[1]) for o in ops if o[0] == F.OP_CHECK)
     return z.Tape.from_parts(hdr, blob)
@@ -477,7 +477,7 @@ def test_many_distinct_circuits_one_launch_full_width(ctx):
         ctx.release(t)
 
 
-@pytest.mark.parametrize("strands", [0, 4])
+@pytest.mark.parametrize("strands", [0, 4, 8])
 def test_deep_gadget_full_size(ctx, strands, interpreter_kernel):
     """The deep chain at its real size: 250 008 constraints over 2^16 vectors, every constraint
     of every vector holds, and the last outputs of sampled vectors match the checker; as a plain

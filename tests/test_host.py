@@ -43,7 +43,7 @@ def test_abi_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_header():
-    assert ctypes.sizeof(api.TapeHdr) == 64
+    assert ctypes.sizeof(api.TapeHdr) == 88
     assert ctypes.sizeof(api.GeneratorConfig) == 20 * 4
     assert ctypes.sizeof(api.LowerOptions) == 10 * 4
 

@@ -348,19 +348,24 @@ def test_operand_registers_are_reused_and_invalidated():
 
 # ---- strand tapes: four wavefronts, one lane of each, sharing LDS and the output buffer -------------
 def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, n_xslots, vec, lane=0):
+    """One lane of each wavefront (four or eight: len(strand_ops)) with the operands the kernel around the stream gives
+    them: eight wavefronts keep two sets of slot rows, wavefronts 4..7 use the second."""
     n_vec = len(inputs)
+    n_str = len(strand_ops)
+    sets = 2 if n_str == 8 else 1
     gs_bytes = n_gslots * SLOT
-    mem, out_region = make_memory(ops, consts, inputs, n_outputs, GS_BASE, gs_bytes)
+    mem, out_region = make_memory(ops, consts, inputs, n_outputs, GS_BASE, sets * gs_bytes)
     shared_lds = table_lds()
-    lds_base = TAB_BASE + TAB_BYTES
-    xbase = lds_base + n_lslots * SLOT
+    lds_rows = TAB_BASE + TAB_BYTES
+    xbase = lds_rows + sets * n_lslots * SLOT
     lanes, pcs, begin = [], [], 0
-    for w in range(4):
+    for w in range(n_str):
         operands = {
             "%[ops]": OPS_BASE + 16 * begin, "%[n_ops]": strand_ops[w], "%[consts]": CST_BASE, "%[n_consts]": len(consts),
-            "%[gslots]": GS_BASE, "%[gslot_bytes]": gs_bytes, "%[lds_base]": lds_base, "%[lds_tab]": TAB_BASE, "%[evict_below]": 0,
+            "%[gslots]": GS_BASE + (w >> 2) * gs_bytes, "%[gslot_bytes]": gs_bytes,
+            "%[lds_base]": lds_rows + (w >> 2) * n_lslots * SLOT, "%[lds_tab]": TAB_BASE, "%[evict_below]": 0,
             "%[in_base]": IN_BASE, "%[out_base]": OUT_BASE, "%[n4]": 4 * n_vec, "%[live]": 0x8000000000000001 | (1 << lane),
-            "%[v_lo]": w * WAVE + lane * 16, "%[v_lo4]": w * WAVE + 2048 + lane * 4, "%[v_vec4]": 4 * vec,
+            "%[v_lo]": (w & 3) * WAVE + lane * 16, "%[v_lo4]": (w & 3) * WAVE + 2048 + lane * 4, "%[v_vec4]": 4 * vec,
             "%[xbase]": xbase, "%[v_x]": lane * 16, "%[v_x4]": 2048 + lane * 4,
         }
         ln = make_lane(mem, xbase + n_xslots * WAVE, lane, operands)
@@ -368,9 +373,9 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
         lanes.append(ln)
         pcs.append(0)
         begin += strand_ops[w]
-    arrived = [0] * 4
+    arrived = [0] * n_str
     while any(pc is not None for pc in pcs):
-        for w in range(4):
+        for w in range(n_str):
             if pcs[w] is not None:
                 pcs[w] = lanes[w].run(PROG, LABELS, pc=pcs[w], stop_at_barrier=True)
                 arrived[w] += pcs[w] is not None
@@ -380,10 +385,11 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
     return outs, sum(ln.operand_written["%[unsat]"] for ln in lanes), min(ln.operand_written["%[first]"] for ln in lanes)
 
 
-def test_strand_tapes_on_the_model():
+@pytest.mark.parametrize("n_strands", [4, 8])
+def test_strand_tapes_on_the_model(n_strands):
     import zkir_amd as z
     o = z.default_lower_options()
-    o.strands = 4
+    o.strands = n_strands
     rnd = random.Random(21)
     g = z.default_generator_config()
     g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware, g.no_loops, g.safe_array_index = 4, 1, 1, 1, 1, 1
@@ -393,7 +399,8 @@ def test_strand_tapes_on_the_model():
     for circuit, n_in in circuits:
         t = z.Lowerer(circuit, o).lower()
         assert t.hdr.flags & 1
-        ops, consts, so = t.ops(), t.consts(), list(t.hdr.strand_ops)
+        ops, consts, so = t.ops(), t.consts(), list(t.hdr.strand_ops)[:t.hdr.n_strands]
+        assert len(so) == n_strands
         inputs = [[rnd.randrange(F.P) for _ in range(n_in)] for _ in range(3)]
         for vec, lane in ((0, 0), (2, 37)):
             want, want_unsat, _ = F.eval_tape_one(ops, consts, inputs[vec], strand_ops=so)

@@ -321,8 +321,12 @@ def test_operand_registers_are_reused_and_invalidated():
 
 # ---- strand tapes: four wavefronts, one lane of each, sharing LDS and the output buffer -------------
 def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, n_xslots, vec, lane=0):
-    """The same lane of the four wavefronts of a workgroup, each running its strand of `ops` from barrier to
-    barrier in turn.  Returns (outputs, unsat summed over the strands, smallest first-unsat)."""
+    """The same lane of the wavefronts of a workgroup (four or eight: len(strand_ops)), each running its strand of
+    `ops` from barrier to barrier in turn, with the operands the kernel around the stream gives them (eight
+    wavefronts keep two sets of slot rows: wavefronts 4..7 use the second).
+    Returns (outputs, unsat summed over the strands, smallest first-unsat)."""
+    n_str = len(strand_ops)
+    sets = 2 if n_str == 8 else 1
     n_vec, n_inputs = len(inputs), len(inputs[0])
     mem = IM.Memory()
     words = []
@@ -334,7 +338,7 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
         cw += F.limbs32(c * R % F.P)
     mem.map("consts", CST_BASE, max(32, 32 * len(consts)), words=cw)
     gs_bytes = n_gslots * 8192
-    mem.map("gslots", GS_BASE, max(gs_bytes, 16), writable=True)
+    mem.map("gslots", GS_BASE, max(sets * gs_bytes, 16), writable=True)
     iw = [0] * (n_inputs * 8 * n_vec)
     for t, vecvals in enumerate(inputs):
         for s, x in enumerate(vecvals):
@@ -344,23 +348,24 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
     out_region = mem.map("outputs", OUT_BASE, max(16, 32 * n_outputs * n_vec), writable=True)
     shared_lds = {}
     lanes, pcs, begin = [], [], 0
-    for w in range(4):
+    for w in range(n_str):
         operands = {
             "%[ops]": OPS_BASE + 16 * begin, "%[n_ops]": strand_ops[w], "%[consts]": CST_BASE, "%[n_consts]": len(consts),
-            "%[gslots]": GS_BASE, "%[gslot_bytes]": gs_bytes, "%[lds_base]": LDS_BASE, "%[evict_below]": 0,
+            "%[gslots]": GS_BASE + (w >> 2) * gs_bytes, "%[gslot_bytes]": gs_bytes,
+            "%[lds_base]": LDS_BASE + (w >> 2) * n_lslots * 8192, "%[evict_below]": 0,
             "%[in_base]": IN_BASE, "%[out_base]": OUT_BASE, "%[n4]": 4 * n_vec, "%[live]": 0x8000000000000001 | (1 << lane),
-            "%[v_lo]": w * 2048 + lane * 16, "%[v_vec4]": 4 * vec,
-            "%[xbase]": LDS_BASE + n_lslots * 8192, "%[v_x]": lane * 16,
+            "%[v_lo]": (w & 3) * 2048 + lane * 16, "%[v_vec4]": 4 * vec,
+            "%[xbase]": LDS_BASE + sets * n_lslots * 8192, "%[v_x]": lane * 16,
         }
-        ln = IM.Lane(mem, LDS_BASE + n_lslots * 8192 + n_xslots * 2048, lane, operands, set(range(G.VB, G.V_LAST + 1)),
+        ln = IM.Lane(mem, LDS_BASE + sets * n_lslots * 8192 + n_xslots * 2048, lane, operands, set(range(G.VB, G.V_LAST + 1)),
                      set(range(G.SB, G.S_LAST + 1)), result_operands=("%[unsat]", "%[first]"))
         ln.lds = shared_lds
         lanes.append(ln)
         pcs.append(0)
         begin += strand_ops[w]
-    arrived = [0] * 4
+    arrived = [0] * n_str
     while any(pc is not None for pc in pcs):
-        for w in range(4):
+        for w in range(n_str):
             if pcs[w] is not None:
                 pcs[w] = lanes[w].run(PROG, LABELS, pc=pcs[w], stop_at_barrier=True)
                 arrived[w] += pcs[w] is not None
@@ -375,13 +380,14 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
     return outs, unsat, first
 
 
-def test_strand_tapes_on_the_model():
+@pytest.mark.parametrize("n_strands", [4, 8])
+def test_strand_tapes_on_the_model(n_strands):
     """Gadget and generated circuits lowered into strand tapes: the stream, run for one lane of each of
     the four wavefronts with LDS shared between them, gives the big-integer interpreter's outputs;
     a planted wrong `c` operand is reported under the constraint number its CHECK op carries."""
     import zkir_amd as z
     o = z.default_lower_options()
-    o.strands = 4
+    o.strands = n_strands
     rnd = random.Random(21)
     g = z.default_generator_config()
     g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware, g.no_loops, g.safe_array_index = 4, 1, 1, 1, 1, 1
@@ -391,7 +397,8 @@ def test_strand_tapes_on_the_model():
     for circuit, n_in in circuits:
         t = z.Lowerer(circuit, o).lower()
         assert t.hdr.flags & 1
-        ops, consts, so = t.ops(), t.consts(), list(t.hdr.strand_ops)
+        ops, consts, so = t.ops(), t.consts(), list(t.hdr.strand_ops)[:t.hdr.n_strands]
+        assert len(so) == n_strands
         inputs = [[rnd.randrange(F.P) for _ in range(n_in)] for _ in range(3)]
         for vec, lane in ((0, 0), (2, 37)):
             want, want_unsat, _ = F.eval_tape_one(ops, consts, inputs[vec], strand_ops=so)

@@ -26,16 +26,17 @@ BAR = (F.OP_BARRIER, NONE, NONE, NONE)
 def strand_tape(strands, consts, n_inputs, n_outputs, n_g, n_l, n_x):
     ops = [o for s in strands for o in s]
     checks = sorted((o[0] >> 8, o) for o in ops if o[0] & 0xFF == F.OP_CHECK)
-    hdr = api.TapeHdr(0x31544B5A, 1, n_inputs, n_outputs, len(consts), len(ops), n_g, n_l, len(checks), 0, 1,
-                      (ctypes_u32x4(*[len(s) for s in strands])), n_x)
+    hdr = api.TapeHdr(0x31544B5A, 2, n_inputs, n_outputs, len(consts), len(ops), n_g, n_l, len(checks), 0, 1,
+                      (ctypes_u32x4(*[len(s) for s in strands])), n_x, len(strands), 0)
     blob = b"".join(struct.pack("<4I", *o) for o in ops) + b"".join(struct.pack("<8I", *F.limbs32(c)) for c in consts)
     blob += b"".join(struct.pack("<3I", o[2], o[3], o[1]) for _, o in checks)
     return hdr, blob
 
 
-def ctypes_u32x4(a, b, c, d):
+def ctypes_u32x4(*counts):
+    """The header's strand_ops field: eight entries, the unused ones zero."""
     import ctypes
-    return (ctypes.c_uint32 * 4)(a, b, c, d)
+    return (ctypes.c_uint32 * 8)(*counts)
 
 
 def hand_strands(bad_check=False):
@@ -62,7 +63,7 @@ def test_checkers_agree_on_a_hand_written_strand_tape():
     for t, (a, b) in enumerate(vecs):
         want = [a * b % F.P, (a + b) % F.P, (a - b) ** 2 % F.P, 7 * a * b % F.P]
         assert got[t] == want
-        o_py, u_py, f_py = F.eval_tape_one(ops, [7], [a, b], strand_ops=list(hdr.strand_ops))
+        o_py, u_py, f_py = F.eval_tape_one(ops, [7], [a, b], strand_ops=list(hdr.strand_ops)[:hdr.n_strands])
         assert [o_py[k] for k in range(4)] == want and u_py == [] and f_py == 0
     assert (unsat, first, faults) == (0, None, 0)
     # a constraint that does not hold is reported under the number its CHECK op carries
@@ -71,7 +72,7 @@ def test_checkers_agree_on_a_hand_written_strand_tape():
     out, unsat, first, faults = C.eval_cpu(bytes(hdr), blob, inp, len(vecs), 4)
     bad = [t for t, (a, b) in enumerate(vecs) if 7 * a * b % F.P != a]
     assert unsat == len(bad) and first == (bad[0], 2)
-    assert F.eval_tape_one(ops, [7], vecs[bad[0]], strand_ops=list(hdr.strand_ops))[1] == [2]
+    assert F.eval_tape_one(ops, [7], vecs[bad[0]], strand_ops=list(hdr.strand_ops)[:hdr.n_strands])[1] == [2]
 
 
 def test_validation_of_strand_tapes():
@@ -101,7 +102,10 @@ def test_validation_of_strand_tapes():
     cases.append(rebuilt(o2))
     cases.append(rebuilt(ops, strand_ops=ctypes_u32x4(6, 5, 6, 4)))  # counts do not add up
     cases.append(rebuilt(ops, flags=0))  # strand fields / exchange operands on a plain tape
-    cases.append(rebuilt(ops, n_xslots=33))
+    cases.append(rebuilt(ops, n_xslots=49))
+    cases.append(rebuilt(ops, n_strands=5))  # a strand tape has 4 or 8 strands
+    cases.append(rebuilt(ops, n_strands=8))  # the fifth to eighth hold no barriers
+    cases.append(rebuilt(ops, reserved=1))
     for h, b in cases:
         with pytest.raises(z.ZkirError):
             z.Tape.from_parts(h, b)
@@ -152,7 +156,8 @@ def _circuits():
         yield "generated %d" % seed, z.Generator(seed, _ext_config(20 + 7 * seed)).generate(), 6
 
 
-def test_lowering_into_strands_keeps_every_result():
+@pytest.mark.parametrize("n_strands", [4, 8])
+def test_lowering_into_strands_keeps_every_result(n_strands):
     """The strand tape of a circuit gives, vector for vector, the outputs, the unsatisfied count and
     the first unsatisfied pair of its plain tape (C checker), and its ops are the plain tape's ops
     plus barriers."""
@@ -160,7 +165,7 @@ def test_lowering_into_strands_keeps_every_result():
     n_strand_tapes = 0
     for name, circuit, n_in in _circuits():
         plain = z.Lowerer(circuit).lower()
-        st = z.Lowerer(circuit, _strand_options()).lower()
+        st = z.Lowerer(circuit, _strand_options(strands=n_strands)).lower()
         vecs = [[rnd.randrange(F.P) for _ in range(n_in)] for _ in range(11)]
         inp = z.pack_inputs(vecs, n_in)
         want = C.eval_cpu(bytes(plain.hdr), plain.blob(), inp, len(vecs), plain.hdr.n_outputs)
@@ -170,21 +175,26 @@ def test_lowering_into_strands_keeps_every_result():
             n_strand_tapes += 1
             ops = st.ops()
             n_bar = sum(1 for o in ops if o[0] & 0xFF == F.OP_BARRIER)
-            assert n_bar % 4 == 0 and len(ops) - n_bar == plain.hdr.n_ops, name
+            assert st.hdr.n_strands == n_strands and list(st.hdr.strand_ops)[n_strands:] == [0] * (8 - n_strands)
+            assert n_bar % n_strands == 0 and len(ops) - n_bar == plain.hdr.n_ops, name
             assert (st.hdr.n_constraints, st.hdr.n_mul_ops) == (plain.hdr.n_constraints, plain.hdr.n_mul_ops)
-            assert st.hdr.n_xslots <= 32
+            assert st.hdr.n_xslots <= (32 if n_strands == 4 else 48)
+            if n_strands == 8:  # strands 4..7 hold only what defines nothing
+                tail = ops[sum(list(st.hdr.strand_ops)[:4]):]
+                assert all(o[0] & 0xFF in (F.OP_OUTPUT, F.OP_CHECK, F.OP_BARRIER) for o in tail), name
             # the Python interpreter agrees on one vector
-            o_py, u_py, _ = F.eval_tape_one(ops, st.consts(), vecs[0], strand_ops=list(st.hdr.strand_ops))
+            o_py, u_py, _ = F.eval_tape_one(ops, st.consts(), vecs[0], strand_ops=list(st.hdr.strand_ops)[:st.hdr.n_strands])
             assert [o_py[k] for k in range(st.hdr.n_outputs)] == z.unpack_outputs(got[0])[0] and u_py == []
         else:
             assert st.blob() == plain.blob(), name  # fell back: the plain tape, bit for bit
-    assert n_strand_tapes >= 10
+    assert n_strand_tapes >= (10 if n_strands == 4 else 6)
 
 
-def test_a_broken_constraint_keeps_its_number_in_a_strand_tape():
+@pytest.mark.parametrize("n_strands", [4, 8])
+def test_a_broken_constraint_keeps_its_number_in_a_strand_tape(n_strands):
     circuit = z.poseidon_style_gadget(4, 6, 3)
     plain = z.Lowerer(circuit).lower()
-    st = z.Lowerer(circuit, _strand_options()).lower()
+    st = z.Lowerer(circuit, _strand_options(strands=n_strands)).lower()
     assert st.hdr.flags & 1
     rnd = random.Random(2)
     vecs = [[rnd.randrange(F.P) for _ in range(4)] for _ in range(5)]
@@ -221,13 +231,14 @@ def test_strand_lowering_refuses_nothing_and_falls_back():
 
 
 @pytest.mark.gpu
-def test_lowered_strand_tapes_on_the_gpu():
+@pytest.mark.parametrize("n_strands", [4, 8])
+def test_lowered_strand_tapes_on_the_gpu(n_strands):
     rnd = random.Random(10)
     ctx = z.Context(0)
     try:
         n_strand_tapes = 0
         for name, circuit, n_in in _circuits():
-            st = z.Lowerer(circuit, _strand_options()).lower()
+            st = z.Lowerer(circuit, _strand_options(strands=n_strands)).lower()
             n_strand_tapes += st.hdr.flags & 1
             n = rnd.choice([1, 63, 64, 65, 200, 777])
             vecs = [[rnd.randrange(F.P) for _ in range(n_in)] for _ in range(n)]
@@ -238,7 +249,7 @@ def test_lowered_strand_tapes_on_the_gpu():
             o_c, u_c, first_c, f_c = C.eval_cpu(bytes(st.hdr), st.blob(), inp, n, st.hdr.n_outputs)
             assert np.array_equal(out, o_c), name
             assert (unsat, first, faults) == (u_c, first_c, f_c) == (0, None, 0), name
-        assert n_strand_tapes >= 10
+        assert n_strand_tapes >= (10 if n_strands == 4 else 6)
     finally:
         ctx.close()
 
@@ -252,7 +263,9 @@ def test_strand_and_plain_tapes_in_one_call():
         circuits = [z.poseidon_style_gadget(4, 3 + k, k + 1) for k in range(6)]
         strand = [z.Lowerer(c, _strand_options()).lower() for c in circuits]
         plain = [z.Lowerer(c).lower() for c in circuits]
+        strand8 = [z.Lowerer(c, _strand_options(strands=8)).lower() for c in circuits]
         assert all(t.hdr.flags & 1 for t in strand) and not any(t.hdr.flags & 1 for t in plain)
+        assert all(t.hdr.n_strands == 8 for t in strand8)
 
         def broken(t):  # constraint 2 compared with a constant: fails for every vector
             ops = [list(o) for o in t.ops()]
@@ -268,7 +281,9 @@ def test_strand_and_plain_tapes_in_one_call():
 
         n = 130
         rnd = random.Random(3)
-        for tapes in (strand, plain, [strand[0], plain[1], broken(strand[2]), plain[3], strand[4], broken(plain[5])]):
+        mixed2 = [strand[0], plain[1], broken(strand[2]), plain[3], strand[4], broken(plain[5])]
+        mixed3 = [strand8[0], plain[1], broken(strand[2]), strand8[3], strand[4], broken(strand8[5]), broken(plain[0])]  # three launches
+        for tapes in (strand, plain, strand8, mixed2, mixed3):
             tids = ctx.upload_many(tapes)
             blocks, want = [], []
             for t in tapes:
@@ -278,7 +293,7 @@ def test_strand_and_plain_tapes_in_one_call():
                 want.append(C.eval_cpu(bytes(t.hdr), t.blob(), inp, n, t.hdr.n_outputs, want_outputs=False)[1])
             unsat, faults = ctx.eval_multi(tids, np.concatenate(blocks), n)
             assert list(unsat) == want and faults == 0
-            assert sum(1 for u in unsat if u) == (2 if len({t.hdr.flags for t in tapes}) == 2 else 0)
+            assert sum(1 for u in unsat if u) == (2 if tapes is mixed2 else 3 if tapes is mixed3 else 0)
             for tid in tids:
                 ctx.release(tid)
     finally:

@@ -84,7 +84,7 @@ def test_no_alloc_entry_point_matches_the_allocating_one():
         rows = api.lib_noalloc_slot_rows()
         G, I, NONE = (lambda i: F.operand(F.K_GSLOT, i)), (lambda i: F.operand(F.K_INPUT, i)), F.operand(F.K_NONE)
         big_ops = [(F.OP_INPUT, G(rows), I(0), NONE), (F.OP_OUTPUT, 0, G(rows), NONE)]
-        big_hdr = api.TapeHdr(0x31544B5A, 1, 1, 1, 0, len(big_ops), rows + 1, 0, 0, 0, 0)
+        big_hdr = api.TapeHdr(0x31544B5A, 2, 1, 1, 0, len(big_ops), rows + 1, 0, 0, 0, 0)
         big = z.Tape.from_parts(big_hdr, b"".join(struct.pack("<4I", *o) for o in big_ops))
         bid = ctx.upload(big)
         inp = _device_inputs(torch, 1, 10, 6)

@@ -36,7 +36,8 @@ class LowerRejected(ZkirError):
 
 class TapeHdr(ctypes.Structure):
     _fields_ = [(n, c_uint32) for n in ("magic", "version", "n_inputs", "n_outputs", "n_consts", "n_ops", "n_gslots",
-                                        "n_lslots", "n_constraints", "n_mul_ops", "flags")] + [("strand_ops", c_uint32 * 4), ("n_xslots", c_uint32)]
+                                        "n_lslots", "n_constraints", "n_mul_ops", "flags")] + [("strand_ops", c_uint32 * 8), ("n_xslots", c_uint32), ("n_strands", c_uint32),
+                                                                                                ("reserved", c_uint32)]
 
 
 class GeneratorConfig(ctypes.Structure):

@@ -225,7 +225,7 @@ def main(argv=None):
     ap.add_argument("--group", type=int, default=2048,
                     help="circuits per launch (a launch should hold several times the 1 280 workgroups the GPU runs at once)")
     ap.add_argument("--workers", type=int, default=8, help="host threads that generate and lower, per rank")
-    ap.add_argument("--strands", type=int, default=0, choices=[0, 4],
+    ap.add_argument("--strands", type=int, default=0, choices=[0, 4, 8],
                     help="4: ask lower for strand tapes (circuits they do not fit come back as plain tapes); for "
                          "campaigns whose launches leave the GPU short of wavefronts")
     args = ap.parse_args(argv)

@@ -8,7 +8,7 @@
 
 namespace zkir {
 
-// Device-side description of one uploaded tape (104 bytes, read with scalar loads).
+// Device-side description of one uploaded tape (136 bytes, read with scalar loads).
 struct TapeDesc {
   const zkir_op* ops;      // n_ops entries
   const uint32_t* consts;  // n_consts x 8 limbs, Montgomery form
@@ -21,11 +21,11 @@ struct TapeDesc {
   uint32_t n_consts;
   uint32_t n_xslots;       // strand tapes: exchange slots
   uint32_t unsat_index;    // which entry of the launch's per-tape unsat array this tape counts into
-  uint32_t reserved;
-  uint32_t strand_begin[ZKIR_STRANDS];  // strand tapes: first op of each strand
-  uint32_t strand_ops[ZKIR_STRANDS];    // strand tapes: ops of each strand
+  uint32_t n_strands;      // strand tapes: 4 or 8
+  uint32_t strand_begin[ZKIR_MAX_STRANDS];  // strand tapes: first op of each strand
+  uint32_t strand_ops[ZKIR_MAX_STRANDS];    // strand tapes: ops of each strand
   const uint32_t* consts29;             // n_consts x 12 words: 9 limbs of 29 bits, Montgomery form with R = 2^261
 };
-static_assert(sizeof(TapeDesc) == 104, "TapeDesc layout");
+static_assert(sizeof(TapeDesc) == 136, "TapeDesc layout");
 
 }  // namespace zkir

@@ -351,27 +351,33 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
 // Limits the host checks before choosing this kernel: 32 * n_vectors < 2^32.
 #include "interp_core_asm.inc"
 
-// strands != 0: every tape of the launch is a strand tape.  The four wavefronts of a workgroup
-// then run the four op streams of the tape on the SAME 64 vectors (a pass is 64 vectors, not
-// 256), each with its own rows of the slots, and meet in the exchange slots that follow the
-// `lslots` window slots in LDS.  The tape's barriers pair up across the wavefronts because the
-// host only uploads strand tapes whose strands hold the same number of them.
-__global__ void __launch_bounds__(kBlock, 2)
+// strands != 0 (4 or 8): every tape of the launch is a strand tape of that many strands.  The
+// wavefronts of a workgroup (64 x strands threads) then run the op streams of the tape on the
+// SAME 64 vectors (a pass is 64 vectors, not 256), each with its own rows of the slots, and meet
+// in the exchange slots that follow the window slots in LDS.  A slot row holds four wavefronts,
+// so a workgroup of eight keeps two sets of rows, in LDS and in device memory: wavefronts 4..7
+// use the second set (`gslots_per_block` counts both).  The tape's barriers pair up across the
+// wavefronts because the host only uploads strand tapes whose strands hold the same number of them.
+__global__ void __launch_bounds__(2 * kBlock)
 zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_t passes_per_tape,
                         uint64_t n_vectors, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ outputs,
                         uint4* __restrict__ gslot_pool, uint32_t gslots_per_block,
                         uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats,
                         uint32_t* __restrict__ work_counter, uint32_t victim_row, uint32_t strands, uint32_t lslots) {
   __shared__ uint32_t next_item;
-  const uint64_t gslots = (uint64_t)(uintptr_t)(gslot_pool + (size_t)blockIdx.x * gslots_per_block * 2 * kBlock);
-  const uint32_t gslot_bytes = gslots_per_block * (uint32_t)(2 * kBlock * sizeof(uint4));
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const uint32_t row_sets = strands == 8u ? 2u : 1u, set = wave >> 2;  // which set of slot rows this wavefront uses
+  const uint32_t gslots_per_set = gslots_per_block / row_sets;
+  const uint64_t gslots = (uint64_t)(uintptr_t)(gslot_pool + ((size_t)blockIdx.x * gslots_per_block + (size_t)set * gslots_per_set) * 2 * kBlock);
+  const uint32_t gslot_bytes = gslots_per_set * (uint32_t)(2 * kBlock * sizeof(uint4));
   // the low half of a generic pointer into LDS is the LDS byte address; with a victim row the
   // first 8 KiB of the dynamic allocation are that row and the window slots follow
-  const uint32_t lds_base = (uint32_t)(uintptr_t)zkir_lds_slots + (victim_row ? 8192u : 0u);
-  const uint32_t xbase = lds_base + lslots * 8192u;
+  const uint32_t lds_rows = (uint32_t)(uintptr_t)zkir_lds_slots + (victim_row ? 8192u : 0u);
+  // (wave-uniform values an asm statement takes in scalar registers: said so explicitly, or the compiler may keep them in vector ones)
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_rows + set * lslots * 8192u);
+  const uint32_t xbase = __builtin_amdgcn_readfirstlane(lds_rows + row_sets * lslots * 8192u);
   const uint32_t evict_below = victim_row ? 0x20000000u : 0u;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  const uint32_t v_lo = wave * 2048u + lane * 16u, v_x = lane * 16u;
+  const uint32_t v_lo = (wave & 3u) * 2048u + lane * 16u, v_x = lane * 16u;
   const uint32_t n4 = (uint32_t)n_vectors * 4u;
 
   const uint64_t total = (uint64_t)n_tapes * passes_per_tape;
@@ -426,22 +432,25 @@ zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, ui
 constexpr uint32_t kSlot29 = 9216, kWave29 = 2304, kTable29 = 2048;
 __constant__ uint32_t zkir_p29[9] = {ZKIR_FR29_P_LIMBS};
 
-__global__ void __launch_bounds__(kBlock, 2)
+__global__ void __launch_bounds__(2 * kBlock)
 zkir_interp_lean29_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_t passes_per_tape,
                           uint64_t n_vectors, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ outputs,
                           uint4* __restrict__ gslot_pool, uint32_t gslots_per_block,
                           uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats,
                           uint32_t* __restrict__ work_counter, uint32_t victim_row, uint32_t strands, uint32_t lslots) {
   __shared__ uint32_t next_item;
-  const uint64_t gslots = (uint64_t)(uintptr_t)((const char*)gslot_pool + (size_t)blockIdx.x * gslots_per_block * kSlot29);
-  const uint32_t gslot_bytes = gslots_per_block * kSlot29;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const uint32_t row_sets = strands == 8u ? 2u : 1u, set = wave >> 2;  // as in zkir_interp_lean_kernel
+  const uint32_t gslots_per_set = gslots_per_block / row_sets;
+  const uint64_t gslots = (uint64_t)(uintptr_t)((const char*)gslot_pool + ((size_t)blockIdx.x * gslots_per_block + (size_t)set * gslots_per_set) * kSlot29);
+  const uint32_t gslot_bytes = gslots_per_set * kSlot29;
   // LDS: the table of multiples of p, then the victim row (if any), the window slots, the exchange slots
   const uint32_t lds_tab = (uint32_t)(uintptr_t)zkir_lds_slots;
-  const uint32_t lds_base = lds_tab + kTable29 + (victim_row ? kSlot29 : 0u);
-  const uint32_t xbase = lds_base + lslots * kSlot29;
+  const uint32_t lds_rows = lds_tab + kTable29 + (victim_row ? kSlot29 : 0u);
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_rows + set * lslots * kSlot29);
+  const uint32_t xbase = __builtin_amdgcn_readfirstlane(lds_rows + row_sets * lslots * kSlot29);
   const uint32_t evict_below = victim_row ? 0x20000000u : 0u;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  const uint32_t v_lo = wave * kWave29 + lane * 16u, v_lo4 = wave * kWave29 + 2048u + lane * 4u;
+  const uint32_t v_lo = (wave & 3u) * kWave29 + lane * 16u, v_lo4 = (wave & 3u) * kWave29 + 2048u + lane * 4u;
   const uint32_t v_x = lane * 16u, v_x4 = 2048u + lane * 4u;
   const uint32_t n4 = (uint32_t)n_vectors * 4u;
   if (threadIdx.x < 32) {  // entry q: the limbs of q*p, 12 words (9 used)
@@ -634,7 +643,7 @@ static bool interp_victim_row(int variant, uint32_t lslots, uint32_t strands) {
 // dynamic LDS of a workgroup: the window slots, plus the victim row, plus (strand tapes) the
 // exchange slots of 64 lanes x 32 bytes
 static size_t interp_lds_bytes(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots) {
-  const size_t rows = lslots + (interp_victim_row(variant, lslots, strands) ? 1 : 0);
+  const size_t rows = (size_t)lslots * (strands == 8 ? 2 : 1) + (interp_victim_row(variant, lslots, strands) ? 1 : 0);
   if (variant == 3) return kTable29 + rows * kSlot29 + (strands ? (size_t)xslots * kWave29 : 0);
   return rows * 2 * kBlock * sizeof(uint4) + (strands ? (size_t)xslots * 2048 : 0);
 }
@@ -650,6 +659,9 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
   if ((variant == 2 || variant == 3) && n_vectors * 32 >= (1ull << 32)) return hipErrorInvalidValue;
   if ((variant == 2 || variant == 3) && (uint64_t)gslots_per_block * interp_slot_bytes(variant) >= (1ull << 32)) return hipErrorInvalidValue;
   if (strands && variant != 2 && variant != 3) return hipErrorInvalidValue;  // only the generated streams know strand tapes
+  if (strands != 0 && strands != 4 && strands != 8) return hipErrorInvalidValue;
+  if (strands == 8) gslots_per_block *= 2;  // two sets of slot rows (a row holds four wavefronts)
+  if ((variant == 2 || variant == 3) && (uint64_t)gslots_per_block * interp_slot_bytes(variant) >= (1ull << 32)) return hipErrorInvalidValue;
   if (lds_bytes > 48 * 1024) {  // above the default dynamic-LDS limit the kernel must opt in
     hipError_t e = hipFuncSetAttribute(interp_entry(variant), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -659,13 +671,13 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
   uint32_t victim_row = interp_victim_row(variant, lslots, strands) ? 1u : 0u;
   void* args[] = {&tapes_dev, &n_tapes, &passes_per_tape, &n_vectors, &inputs, &outputs, &pool, &gslots_per_block,
                   &unsat_per_tape, &stats, &work_counter, &victim_row, &strands, &lslots};
-  return hipLaunchKernel(interp_entry(variant), dim3(grid), dim3(kBlock), args, lds_bytes, stream);
+  return hipLaunchKernel(interp_entry(variant), dim3(grid), dim3(strands == 8 ? 2 * kBlock : kBlock), args, lds_bytes, stream);
 }
 
 // workgroups of the interpreter that fit on one CU with `lslots` window slots
 hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots, int* blocks) {
   const size_t lds_bytes = interp_lds_bytes(variant, lslots, strands, xslots);
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, interp_entry(variant), kBlock, lds_bytes);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, interp_entry(variant), strands == 8 ? 2 * kBlock : kBlock, lds_bytes);
   if (e == hipSuccess && *blocks < 1) *blocks = 1;
   return e;
 }

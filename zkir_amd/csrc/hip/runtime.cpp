@@ -199,8 +199,9 @@ TapeDesc make_desc(const DevTape& t, uint32_t index, uint64_t in_off, uint64_t o
   d.unsat_index = index;
   if (t.hdr.flags & ZKIR_TAPE_F_STRANDS) {
     d.n_xslots = t.hdr.n_xslots;
+    d.n_strands = t.hdr.n_strands;
     uint32_t begin = 0;
-    for (uint32_t s = 0; s < ZKIR_STRANDS; s++) {
+    for (uint32_t s = 0; s < t.hdr.n_strands && s < ZKIR_MAX_STRANDS; s++) {
       d.strand_begin[s] = begin;
       d.strand_ops[s] = t.hdr.strand_ops[s];
       begin += t.hdr.strand_ops[s];
@@ -248,8 +249,13 @@ int pick_variant(bool full, uint64_t N, uint32_t max_gslots) {
 }
 
 // The tapes of one kind in a call: plain tapes run 256 vectors per workgroup, strand tapes 64 (their
-// four wavefronts are the four strands), so a call that holds both becomes two launches on the same
-// stream.
+// four or eight wavefronts are the strands), so a call that holds several kinds becomes one launch per
+// kind on the same stream.  Kinds: 0 plain, 1 four strands, 2 eight strands.
+constexpr int kKinds = 3;
+inline int kind_of(const zkir_tape_hdr& h) { return !(h.flags & ZKIR_TAPE_F_STRANDS) ? 0 : h.n_strands == ZKIR_MAX_STRANDS ? 2 : 1; }
+inline uint32_t strands_of_kind(int kind) { return kind == 0 ? 0u : kind == 1 ? ZKIR_STRANDS : ZKIR_MAX_STRANDS; }
+// sets of slot rows a workgroup keeps (a row holds four wavefronts)
+inline uint32_t row_sets_of_kind(int kind) { return kind == 2 ? 2u : 1u; }
 struct Group {
   uint32_t count = 0;
   bool full = false;
@@ -269,8 +275,8 @@ struct Plan {
 
 // pool_rows_cap: 0, or the slot rows (8 KiB each) the caller's fixed pool holds; the grid shrinks to fit
 int32_t plan_group(zkir_ctx* ctx, const Group& G, int kind, uint64_t N, size_t pool_rows_cap, Plan* P) {
-  P->strands = (uint32_t)kind;
-  // a pass is one workgroup's worth of vectors: 256, or 64 when its four wavefronts are the four strands
+  P->strands = strands_of_kind(kind);
+  // a pass is one workgroup's worth of vectors: 256, or 64 when its wavefronts are the strands
   const uint32_t per_pass = kind ? 64u : (uint32_t)ZKIR_BLOCK_THREADS;
   P->passes = (uint32_t)((N + per_pass - 1) / per_pass);
   const uint64_t work = (uint64_t)G.count * P->passes;
@@ -287,10 +293,11 @@ int32_t plan_group(zkir_ctx* ctx, const Group& G, int kind, uint64_t N, size_t p
   }
   P->grid = pick_grid(ctx, work, P->variant, G.max_lslots, P->strands, G.max_xslots);
   if (pool_rows_cap && G.max_gslots) {
-    if (G.max_gslots > pool_rows_cap)
-      return fail(ctx, ZKIR_E_LIMIT, "the tape needs " + std::to_string(G.max_gslots) + " device slots; the fixed scratch holds " +
+    const uint64_t rows = (uint64_t)G.max_gslots * row_sets_of_kind(kind);
+    if (rows > pool_rows_cap)
+      return fail(ctx, ZKIR_E_LIMIT, "the tape needs " + std::to_string(rows) + " device slot rows; the fixed scratch holds " +
                                          std::to_string(pool_rows_cap));
-    P->grid = (uint32_t)std::min<uint64_t>(P->grid, pool_rows_cap / G.max_gslots);
+    P->grid = (uint32_t)std::min<uint64_t>(P->grid, pool_rows_cap / rows);
   }
   return ZKIR_OK;
 }
@@ -343,7 +350,7 @@ int32_t run_one(zkir_ctx* ctx, const DevTape& t, const uint32_t* in_dev, uint64_
   Group G;
   G.add(t);
   Plan P;
-  const int kind = (t.hdr.flags & ZKIR_TAPE_F_STRANDS) ? 1 : 0;
+  const int kind = kind_of(t.hdr);
   const size_t rows_cap = fixed_scratch ? (fixed_bytes - kSlotBytesMax) / kSlotBytesMax : 0;
   int32_t rc = plan_group(ctx, G, kind, N, rows_cap, &P);
   if (rc) return rc;
@@ -353,7 +360,8 @@ int32_t run_one(zkir_ctx* ctx, const DevTape& t, const uint32_t* in_dev, uint64_
     counter = (uint32_t*)fixed_scratch;
     pool = fixed_scratch + kSlotBytesMax;
   } else {
-    rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, (size_t)P.grid * G.max_gslots * zkir::interp_slot_bytes(P.variant));
+    rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes,
+                (size_t)P.grid * G.max_gslots * row_sets_of_kind(kind) * zkir::interp_slot_bytes(P.variant));
     if (rc) return rc;
     counter = (uint32_t*)ctx->work_counter;
     pool = ctx->gslot_pool;
@@ -395,35 +403,36 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
                   uint32_t* out_dev, uint64_t* unsat_dev, uint64_t* stats_dev, hipStream_t stream) {
   if (N == 0 || n == 0) return ZKIR_OK;
   if (N >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "N must be below 2^32");
-  Group G[2];
-  // descriptors in call order, plain tapes from the front, strand tapes from the back of one pinned buffer
+  Group G[kKinds];
+  // descriptors of one pinned buffer: the plain tapes in call order, then the four-strand tapes, then the eight-strand ones
   int stage = 0;
   int32_t rc = desc_stage_acquire(ctx, (size_t)n * sizeof(TapeDesc), &stage);
   if (rc) return rc;
   TapeDesc* host_descs = (TapeDesc*)ctx->desc_stage[stage];
-  uint32_t n_strand = 0;
+  uint32_t n_of_kind[kKinds] = {0, 0, 0};
   for (uint32_t i = 0; i < n; i++) {
     auto it = ctx->tapes.find(ids[i]);
     if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
-    if (it->second.hdr.flags & ZKIR_TAPE_F_STRANDS) n_strand++;
+    n_of_kind[kind_of(it->second.hdr)]++;
   }
   uint64_t in_off = 0, out_off = 0;
-  uint32_t at[2] = {0, n - n_strand};
+  uint32_t at[kKinds] = {0, n_of_kind[0], n_of_kind[0] + n_of_kind[1]};
   for (uint32_t i = 0; i < n; i++) {
     const DevTape& t = ctx->tapes.find(ids[i])->second;
-    const int kind = (t.hdr.flags & ZKIR_TAPE_F_STRANDS) ? 1 : 0;
+    const int kind = kind_of(t.hdr);
     G[kind].add(t);
     host_descs[at[kind]++] = make_desc(t, i, in_off, out_off);
     in_off += (uint64_t)t.hdr.n_inputs * 8 * N;
     out_off += (uint64_t)t.hdr.n_outputs * 8 * N;
   }
-  Plan plan[2];
+  Plan plan[kKinds];
   size_t pool_bytes = 0;
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < kKinds; k++) {
     if (!G[k].count) continue;
     rc = plan_group(ctx, G[k], k, N, 0, &plan[k]);
     if (rc) return rc;
-    pool_bytes = std::max(pool_bytes, (size_t)plan[k].grid * G[k].max_gslots * zkir::interp_slot_bytes(plan[k].variant));
+    pool_bytes = std::max(pool_bytes, (size_t)plan[k].grid * G[k].max_gslots * row_sets_of_kind(k) *
+                                          zkir::interp_slot_bytes(plan[k].variant));
   }
   rc = ensure(ctx, &ctx->gslot_pool, &ctx->gslot_pool_bytes, pool_bytes);
   if (rc) return rc;
@@ -431,13 +440,13 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
   if (rc) return rc;
   rc = chain_stream(ctx, stream);
   if (rc) return rc;
-  // the two launches draw work items from two counters (64 bytes apart) zeroed here
+  // the launches draw work items from counters of their own (64 bytes apart) zeroed here
   HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, 256, stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->desc_buf, host_descs, (size_t)n * sizeof(TapeDesc), hipMemcpyHostToDevice, stream));
   HIP_TRY(ctx, hipEventRecord(ctx->desc_copied[stage], stream));
   ctx->desc_copy_recorded[stage] = true;
   size_t desc_at = 0;
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < kKinds; k++) {
     if (!G[k].count) continue;
     rc = launch_group(ctx, G[k], plan[k], (const TapeDesc*)ctx->desc_buf + desc_at, in_dev, N, out_dev, ctx->gslot_pool,
                       (uint32_t*)ctx->work_counter + 16 * k, unsat_dev, stats_dev, stream);

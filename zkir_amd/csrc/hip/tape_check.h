@@ -44,12 +44,19 @@ inline bool check_tape(const zkir_tape_hdr& h, const void* blob, size_t bytes, s
   if (h.n_lslots > ZKIR_MAX_LSLOTS) return bad("too many on-chip slots");
   if (h.flags & ~ZKIR_TAPE_F_STRANDS) return bad("unknown flag bits");
   const bool strands = (h.flags & ZKIR_TAPE_F_STRANDS) != 0;
+  if (h.reserved) return bad("reserved header word set");
+  uint32_t any_strand_ops = 0;
+  for (uint32_t s = 0; s < ZKIR_MAX_STRANDS; s++) any_strand_ops |= h.strand_ops[s];
   if (strands) {
+    if (h.n_strands != ZKIR_STRANDS && h.n_strands != ZKIR_MAX_STRANDS) return bad("a strand tape has 4 or 8 strands");
     uint64_t sum = 0;
-    for (uint32_t s = 0; s < ZKIR_STRANDS; s++) sum += h.strand_ops[s];
+    for (uint32_t s = 0; s < ZKIR_MAX_STRANDS; s++) {
+      if (s >= h.n_strands && h.strand_ops[s]) return bad("op count set for a strand the tape does not have");
+      sum += h.strand_ops[s];
+    }
     if (sum != h.n_ops) return bad("strand op counts do not add up to n_ops");
     if (h.n_xslots > ZKIR_MAX_XSLOTS) return bad("too many exchange slots");
-  } else if (h.strand_ops[0] | h.strand_ops[1] | h.strand_ops[2] | h.strand_ops[3] | h.n_xslots) {
+  } else if (any_strand_ops | h.n_xslots | h.n_strands) {
     return bad("strand fields set on a plain tape");
   }
   if (h.n_ops > (1u << 26) || h.n_consts > (1u << 26) || h.n_gslots > (1u << 24) || h.n_inputs > (1u << 24) ||
@@ -63,12 +70,12 @@ inline bool check_tape(const zkir_tape_hdr& h, const void* blob, size_t bytes, s
   // strand tapes: barriers per strand (all strands must hold the same number, or the
   // wavefronts of a workgroup would wait for each other forever), and every constraint
   // number exactly once
-  uint32_t barriers[ZKIR_STRANDS] = {0, 0, 0, 0};
+  uint32_t barriers[ZKIR_MAX_STRANDS] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t strand = 0, strand_end = strands ? h.strand_ops[0] : h.n_ops;
   std::vector<bool> seen_check(strands ? h.n_constraints : 0, false);
   for (uint32_t i = 0; i < h.n_ops; i++) {
     const zkir_op& op = ops[i];
-    while (strands && i >= strand_end && strand + 1 < ZKIR_STRANDS) strand_end += h.strand_ops[++strand];
+    while (strands && i >= strand_end && strand + 1 < h.n_strands) strand_end += h.strand_ops[++strand];
     const uint32_t code = op.code & 0xffu;
     if (op.code & ~0xffu) {
       if (!(strands && code == ZKIR_OP_CHECK)) return bad("reserved opcode bits set");
@@ -103,8 +110,8 @@ inline bool check_tape(const zkir_tape_hdr& h, const void* blob, size_t bytes, s
     }
   }
   if (checks != h.n_constraints) return bad("n_constraints does not match the CHECK ops");
-  if (strands && (barriers[1] != barriers[0] || barriers[2] != barriers[0] || barriers[3] != barriers[0]))
-    return bad("strands hold different numbers of barriers");
+  for (uint32_t s = 1; strands && s < h.n_strands; s++)
+    if (barriers[s] != barriers[0]) return bad("strands hold different numbers of barriers");
   return true;
 }
 

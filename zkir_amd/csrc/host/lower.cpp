@@ -687,7 +687,7 @@ StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>&
 struct Placement {
   std::vector<uint8_t> strand;             // per op
   std::vector<int32_t> epoch;              // per op
-  std::vector<uint32_t> order[ZKIR_STRANDS];  // ops of each strand in the order they run
+  std::vector<uint32_t> order[ZKIR_MAX_STRANDS];  // ops of each strand in the order they run
   int32_t n_epochs = 1;
 };
 
@@ -932,7 +932,8 @@ void write_tape(Tape& tape, const Pass1& p1, const std::vector<zkir_op>& out_ops
 
 Tape Lowerer::lower() {
   if (opts_.n_lslots > ZKIR_MAX_LSLOTS) throw LowerError(ZKIR_LOWER_BAD_AST, "n_lslots above ZKIR_MAX_LSLOTS");
-  if (opts_.strands != 0 && opts_.strands != ZKIR_STRANDS) throw LowerError(ZKIR_LOWER_BAD_AST, "strands must be 0 or 4");
+  if (opts_.strands != 0 && opts_.strands != ZKIR_STRANDS && opts_.strands != ZKIR_MAX_STRANDS)
+    throw LowerError(ZKIR_LOWER_BAD_AST, "strands must be 0, 4 or 8");
   Pass1 p1(circuit, opts_);
   p1.run();
   const std::vector<SOp>& ops = p1.ops;
@@ -959,9 +960,33 @@ Tape Lowerer::lower() {
   h.n_constraints = n_checks;
   std::vector<uint32_t> triples((size_t)n_checks * 3, 0);
 
-  if (opts_.strands == ZKIR_STRANDS && plain_ops_only && n_checks < (1u << 24) - 1) {
-    const uint32_t max_x = std::min<uint32_t>(opts_.max_xslots ? opts_.max_xslots : ZKIR_MAX_XSLOTS, ZKIR_MAX_XSLOTS);
-    const Placement pl = place_strands(ops, nv);
+  if (opts_.strands && plain_ops_only && n_checks < (1u << 24) - 1) {
+    const int S = (int)opts_.strands;
+    const uint32_t max_x = std::min<uint32_t>(opts_.max_xslots ? opts_.max_xslots : (S == (int)ZKIR_MAX_STRANDS ? ZKIR_MAX_XSLOTS : 32u), ZKIR_MAX_XSLOTS);
+    Placement pl = place_strands(ops, nv);
+    if (S == (int)ZKIR_MAX_STRANDS) {
+      // Eight strands: the four of the schedule above keep every op that defines a value; the ops that define
+      // nothing (OUTPUT, CHECK: more than a third of the work of a circuit of rank-1 constraints) move from strand s
+      // to strand s + 4, one epoch later, when everything they read has crossed a barrier.  The chains of the
+      // circuit advance on four wavefronts while four more check and convert what the last epoch produced: same
+      // barriers, and the two wavefronts that share a SIMD fill each other's issue gaps.
+      bool any_in_last = false;
+      for (int s = 0; s < (int)ZKIR_STRANDS; s++) {
+        std::vector<uint32_t> keep;
+        for (uint32_t i : pl.order[s]) {
+          if (ops[i].code == ZKIR_OP_OUTPUT || ops[i].code == ZKIR_OP_CHECK) {
+            any_in_last = any_in_last || pl.epoch[i] == pl.n_epochs - 1;
+            pl.strand[i] = (uint8_t)(s + (int)ZKIR_STRANDS);
+            pl.epoch[i] += 1;
+            pl.order[s + ZKIR_STRANDS].push_back(i);
+          } else {
+            keep.push_back(i);
+          }
+        }
+        pl.order[s].swap(keep);
+      }
+      if (any_in_last) pl.n_epochs += 1;
+    }
     // values read outside the strand that defines them live in exchange slots.  A slot is free
     // again for a definition in an epoch after the one of its value's last read: every reader
     // has then passed the barrier the writer waits at.
@@ -1013,9 +1038,9 @@ Tape Lowerer::lower() {
       const uint32_t barrier_at = (uint32_t)all.size();
       all.push_back({ZKIR_OP_BARRIER, kNoRef, kNoRef, kNoRef});
       check_id.push_back(0);
-      std::vector<uint32_t> stream[ZKIR_STRANDS];
-      int32_t at_epoch[ZKIR_STRANDS] = {0, 0, 0, 0};
-      for (int s = 0; s < (int)ZKIR_STRANDS; s++)
+      std::vector<uint32_t> stream[ZKIR_MAX_STRANDS];
+      int32_t at_epoch[ZKIR_MAX_STRANDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int s = 0; s < S; s++)
         for (uint32_t i : pl.order[s]) {
           for (; at_epoch[s] < pl.epoch[i]; at_epoch[s]++) stream[s].push_back(barrier_at);
           stream[s].push_back(i);
@@ -1029,9 +1054,12 @@ Tape Lowerer::lower() {
       // wavefronts hide.  Measured on the gadget (8 exchange slots): two window rows beat three from
       // 2^17 vectors on (178 against 211 ms) and cost 2 % at 2^16.
       LowerOptions sopts = opts_;
-      const uint32_t x_bytes = (uint32_t)slot_free_from.size() * 2048u, budget = 32u * 1024u;
-      sopts.n_lslots = std::min<uint32_t>(opts_.n_lslots, x_bytes >= budget ? 0u : (budget - x_bytes) / 8192u);
-      for (int s = 0; s < (int)ZKIR_STRANDS; s++) {
+      // Eight strands keep two sets of rows (a row holds four wavefronts), need more exchange slots (what the
+      // second four read has to cross) and are for the smallest batches, where a CU holds one workgroup: 96 KiB.
+      const uint32_t x_bytes = (uint32_t)slot_free_from.size() * 2048u, budget = (S == 8 ? 96u : 32u) * 1024u;
+      const uint32_t row_bytes = 8192u * (S == 8 ? 2u : 1u);
+      sopts.n_lslots = std::min<uint32_t>(opts_.n_lslots, x_bytes >= budget ? 0u : (budget - x_bytes) / row_bytes);
+      for (int s = 0; s < S; s++) {
         for (; at_epoch[s] < pl.n_epochs - 1; at_epoch[s]++) stream[s].push_back(barrier_at);
         StreamOut so = place_stream(all, stream[s], nv, xhome, check_id, true, sopts, &triples);
         h.strand_ops[s] = (uint32_t)so.ops.size();
@@ -1041,6 +1069,7 @@ Tape Lowerer::lower() {
         out_ops.insert(out_ops.end(), so.ops.begin(), so.ops.end());
       }
       h.flags = ZKIR_TAPE_F_STRANDS;
+      h.n_strands = (uint32_t)S;
       h.n_xslots = (uint32_t)slot_free_from.size();
       h.n_ops = (uint32_t)out_ops.size();
       h.n_mul_ops = n_mul;
