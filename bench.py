@@ -141,7 +141,7 @@ def main():
                     help="split the 2^log2-vectors batch over the ranks (contiguous ranges) instead of giving every "
                          "rank a batch of that size: the fixed-size reading of configs 2 and 5")
     ap.add_argument("--strands", default="auto", choices=["auto", "0", "4", "8"],
-                    help="gadget only: lower into a strand tape (4, and auto) or a plain tape (0)")
+                    help="gadget only: lower into a strand tape of 4 or 8 strands (auto: 8 up to 2^14 vectors per GPU, else 4) or a plain tape (0)")
     ap.add_argument("--signal-window", type=int, default=0,
                     help="config2 only: linear terms read the inputs and the last W signals instead of any "
                          "earlier signal (0 = any, the default line)")
@@ -257,7 +257,8 @@ def main():
         n //= world  # this rank's contiguous range of the batch
     # measured (profiles/r01_f_gadget_strands_vs_plain.txt): the gadget's strand tape beats its plain tape at every
     # batch size from 2^13 to 2^21 vectors, by 4x where the plain tape leaves SIMDs without a wavefront
-    strands = 4 if args.strands == "auto" else int(args.strands)
+    # and (profiles/r02_d_strands8.txt) eight strands beat four up to 2^14 vectors per GPU (26.9 against 38.2 ms for 4 000 rounds)
+    strands = (8 if n <= (1 << 14) else 4) if args.strands == "auto" else int(args.strands)
     tape = gadget_tape(z, args.gadget_rounds, strands) if gadget else workload_tape(z, args.signal_window, args.linear_terms)
     h = tape.hdr
     want_outputs = not gadget and not args.no_outputs
@@ -275,7 +276,7 @@ def main():
             fr = (hh.n_mul_ops + hh.n_constraints) * n_rank
             return {"workload": name, "scaling": scaling, "value": mm["checks"] / mm["elapsed"], "unit": "checks/s",
                     "ms_per_step": 1e3 * mm["elapsed"] / steps, "kernel_ms": mm["kernel_ms"], "vectors_per_gpu": n_rank,
-                    "n_constraints": hh.n_constraints, "strand_tape": bool(hh.flags & 1),
+                    "n_constraints": hh.n_constraints, "strand_tape": bool(hh.flags & 1), "strands": hh.n_strands,
                     "fr_mul_per_s": fr * world / (mm["elapsed"] / steps),
                     "mulhi_frac": 128.0 * fr / (mm["kernel_ms"] * 1e-3) / mulhi_peak_x}
 
@@ -286,8 +287,8 @@ def main():
                               % LOG2_VECTORS, tape, mm, n2, args.steps, "strong"))
         if (1 << 16) % world == 0:
             g_rounds = 20 if dry else args.gadget_rounds
-            gt = gadget_tape(z, g_rounds, 4)
             n5 = (1 << (8 if dry else 16)) // world
+            gt = gadget_tape(z, g_rounds, 8 if n5 <= (1 << 14) and not dry else 4)
             k5 = max(1, min(args.steps, 5))
             mm = measure(gt, n5, False, k5, 1, 3000 + rank)
             assert mm["unsat"] == 0
@@ -376,7 +377,7 @@ def main():
                 "n_constraints": h.n_constraints, "n_mul_ops": h.n_mul_ops, "n_ops": h.n_ops,
                 "n_inputs": h.n_inputs, "n_outputs": h.n_outputs, "vectors_per_gpu": n,
                 "device_slots": h.n_gslots, "window_slots": h.n_lslots,
-                "strand_tape": bool(h.flags & 1), "exchange_slots": h.n_xslots,
+                "strand_tape": bool(h.flags & 1), "strands": h.n_strands, "exchange_slots": h.n_xslots,
             },
             "fr_mul_per_s": fr_muls * world / (1e3 * elapsed / args.steps * 1e-3),
             "roofline": {
