@@ -293,6 +293,14 @@ typedef struct zkir_lower_options {
                               slots; 0: one op stream                           */
   uint32_t max_xslots;     /* exchange slots a strand tape may use (0 = 32, or
                               ZKIR_MAX_XSLOTS with 8 strands)                   */
+  uint32_t reorder;        /* 1: a plain tape runs the circuit's statements in the
+                              order that reads most operands from registers and
+                              the window (CHECK ops then carry their constraint
+                              numbers, as in strand tapes); 0: program order    */
+  uint32_t window_cache;   /* 1: plain tapes keep in the window, at every point,
+                              the values read soonest (a value read again later
+                              is also copied to a device slot); 0: a value lives
+                              in the window or in device memory for all its life */
 } zkir_lower_options;
 
 int32_t zkir_lower_options_default(zkir_lower_options* o);

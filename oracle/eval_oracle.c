@@ -213,7 +213,8 @@ static void store_soa(uint32_t* base, uint64_t N, uint64_t elem, uint64_t t, con
  * exchange slots x[]; they are run here one after the other from barrier to barrier, which
  * is one of the interleavings the tape's rules allow (a strand reads an exchange slot only
  * after the barrier that follows its write), so any correct parallel run gives the same values.
- * The constraint number of a CHECK is its position in a plain tape, (code >> 8) - 1 in a strand tape.
+ * The constraint number of a CHECK is (code >> 8) - 1 when the op carries one (every strand tape, reordered plain
+ * tapes), else its position among the CHECK ops.
  */
 static void* run_range(void* arg) {
   job_t* j = (job_t*)arg;
@@ -252,7 +253,7 @@ static void* run_range(void* arg) {
             continue;
           } else if (code == OP_CHECK) {
             fe v; f_mul(&v, SRC(op->a), SRC(op->b));
-            const uint64_t id = strands == 1 ? k : (uint64_t)(op->code >> 8) - 1;
+            const uint64_t id = (op->code >> 8) ? (uint64_t)(op->code >> 8) - 1 : k;
             if (!eq(&v, SRC(op->dst))) {
               j->unsat++;
               if (id < first_k) first_k = id;

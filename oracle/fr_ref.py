@@ -234,7 +234,7 @@ def eval_tape_one(ops, consts, inputs, strand_ops=None):
                     outputs[dst] = rd(st, a)
                 elif code == OP_CHECK:
                     if mul(rd(st, a), rd(st, b)) != rd(st, dst):
-                        unsat.append((full >> 8) - 1 if strand_ops else k)
+                        unsat.append((full >> 8) - 1 if full >> 8 else k)
                     k += 1
                 elif code in UNARY:
                     st["acc"] = UNARY[code](rd(st, a))

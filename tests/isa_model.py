@@ -387,6 +387,8 @@ class Lane:
             if op == "v_ashrrev_i32" and x >> 31:
                 x -= 1 << 32
             self.vwrite(a[0], (x >> sh) & M32)
+        elif op == "v_lshlrev_b32":
+            self.vwrite(a[0], (self.vread(a[2]) << (self.vread(a[1]) & 31)) & M32)
         elif op == "v_lshrrev_b64":
             lo, hi = self.vrange(a[2], 2)
             v = (self.vread(lo) | (self.vread(hi) << 32)) >> (self.vread(a[1]) & 63)

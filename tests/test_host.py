@@ -45,7 +45,7 @@ def test_abi_exports_every_declared_symbol():
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(api.TapeHdr) == 88
     assert ctypes.sizeof(api.GeneratorConfig) == 20 * 4
-    assert ctypes.sizeof(api.LowerOptions) == 10 * 4
+    assert ctypes.sizeof(api.LowerOptions) == 12 * 4
 
 
 def test_default_config_is_the_reference_literals():
@@ -280,8 +280,10 @@ def test_lower_matches_ast_interpreter_extended():
             assert unsat == it.unsat() == []
             assert tape.hdr.n_constraints == len(it.constraints)
             # the triples table repeats the operands of the CHECK ops, in order
-            checks = [(op[2], op[3], op[1]) for op in tape.ops() if op[0] == F.OP_CHECK]
-            assert checks == tape.triples()
+            # (a reordered tape's CHECK ops carry their constraint number + 1 above the opcode)
+            checks = [((op[0] >> 8) - 1 if op[0] >> 8 else k, (op[2], op[3], op[1]))
+                      for k, op in enumerate(o for o in tape.ops() if o[0] & 0xFF == F.OP_CHECK)]
+            assert [c for _, c in sorted(checks)] == tape.triples()
             # the C interpreter agrees with the big-integer one on the same tape
             n = 3
             vecs = [inputs] + [[rnd.randrange(F.P) for _ in inputs] for _ in range(n - 1)]
@@ -350,6 +352,64 @@ def test_slot_allocation_options_do_not_change_results():
         if not reuse and not nl:
             assert t.hdr.n_gslots >= 250  # one slot per stored value
     assert z.Lowerer(c, None).lower().hdr.n_constraints > 20
+
+
+def test_statement_order_and_window_policy_do_not_change_results():
+    """A plain tape with its statements reordered and its window run as a cache gives, vector for vector, the outputs,
+    the unsatisfied pairs and the first unsatisfied pair of the tape in program order (C checker, Python interpreter);
+    a broken constraint keeps its number; the reordered tape moves fewer values through device slots."""
+    import struct
+    import numpy as np
+    sys_path_tools = os.path.join(ROOT, "tools")
+    import sys
+    sys.path.insert(0, sys_path_tools)
+    from slot_traffic import slot_traffic
+    rnd = random.Random(4)
+    for seed, n_instr in ((5, 300), (9, 800), (11, 60)):
+        cfg = dict(EXT, arithmetic_only=1, quadratic_aware=1, no_loops=1, min_instructions=n_instr, max_instructions=n_instr)
+        c = z.Generator(seed, ext_config(**cfg)).generate()
+        tapes = {}
+        for reorder, cache in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            o = z.default_lower_options()
+            o.reorder, o.window_cache = reorder, cache
+            tapes[reorder, cache] = z.Lowerer(c, o).lower()
+        ref = tapes[0, 0]
+        assert not any(op[0] >> 8 for op in ref.ops()) and all(op[0] >> 8 for op in tapes[1, 1].ops() if op[0] & 0xFF == F.OP_CHECK)
+        vecs = [[rnd.randrange(F.P) for _ in range(ref.hdr.n_inputs)] for _ in range(9)]
+        inp = z.pack_inputs(vecs, ref.hdr.n_inputs)
+
+        def broken(t, number):  # the c operand of one constraint replaced by a constant: it fails for every vector
+            ops, k = [list(op) for op in t.ops()], 0
+            for op in ops:
+                if op[0] & 0xFF == F.OP_CHECK:
+                    if ((op[0] >> 8) - 1 if op[0] >> 8 else k) == number:
+                        op[1] = F.operand(F.K_CONST, 0)
+                    k += 1
+            return b"".join(struct.pack("<4I", *op) for op in ops) + t.blob()[16 * t.hdr.n_ops:]
+
+        n_con = ref.hdr.n_constraints
+        want = C.eval_cpu(bytes(ref.hdr), ref.blob(), inp, len(vecs), ref.hdr.n_outputs)
+        want_bad = C.eval_cpu(bytes(ref.hdr), broken(ref, n_con // 2), inp, len(vecs), ref.hdr.n_outputs)
+        assert want[1] == 0 and want_bad[1] == len(vecs) and want_bad[2] == (0, n_con // 2)
+        for key, t in tapes.items():
+            assert (t.hdr.n_constraints, t.hdr.n_mul_ops, t.hdr.n_outputs) == (n_con, ref.hdr.n_mul_ops, ref.hdr.n_outputs)
+            got = C.eval_cpu(bytes(t.hdr), t.blob(), inp, len(vecs), t.hdr.n_outputs)
+            assert np.array_equal(got[0], want[0]) and got[1:] == want[1:], key
+            got_bad = C.eval_cpu(bytes(t.hdr), broken(t, n_con // 2), inp, len(vecs), t.hdr.n_outputs)
+            assert np.array_equal(got_bad[0], want_bad[0]) and got_bad[1:] == want_bad[1:], key
+            assert F.eval_tape_one(t.ops(), t.consts(), vecs[0]) == F.eval_tape_one(ref.ops(), ref.consts(), vecs[0])
+            z.Tape.from_parts(t.hdr, t.blob())  # validation accepts numbered CHECK ops in a plain tape
+        if n_instr >= 300:
+            r0, w0, _ = slot_traffic(tapes[0, 0].ops())
+            r1, w1, _ = slot_traffic(tapes[1, 1].ops())
+            assert r1 + w1 < 0.85 * (r0 + w0), (r0, w0, r1, w1)
+    # numbers on some CHECK ops only: refused
+    t = tapes[1, 1]
+    ops = [list(op) for op in t.ops()]
+    k = next(i for i, op in enumerate(ops) if op[0] & 0xFF == F.OP_CHECK)
+    ops[k][0] &= 0xFF
+    with pytest.raises(z.ZkirError):
+        z.Tape.from_parts(t.hdr, b"".join(struct.pack("<4I", *op) for op in ops) + t.blob()[16 * t.hdr.n_ops:])
 
 
 def test_tape_validation_rejects_out_of_range_operands():

@@ -66,7 +66,7 @@ def run_lane(ops, consts, inputs, n_outputs, n_lslots, n_gslots, vec, wave=0, la
         "%[xbase]": LDS_BASE + (n_lslots + (1 if victim else 0)) * 8192, "%[v_x]": lane * 16,
     }
     ln = IM.Lane(mem, LDS_BASE + (n_lslots + (1 if victim else 0)) * 8192 + n_xslots * 2048, lane, operands, set(range(G.VB, G.V_LAST + 1)),
-                 set(range(G.SB, G.S_LAST + 1)), result_operands=("%[unsat]", "%[first]"))
+                 set(range(G.S_FIRST, G.S_LAST + 1)), result_operands=("%[unsat]", "%[first]"))
     ln.run(PROG, LABELS)
     outs = None
     if want_outputs and live:
@@ -233,26 +233,24 @@ def test_register_discipline():
         for m in re.finditer(r"\bv\[(\d+):(\d+)\]", l):
             assert G.VB <= int(m.group(1)) and int(m.group(2)) <= G.V_LAST, l
         for m in re.finditer(r"\bs(\d+)\b", l):
-            assert G.SB <= int(m.group(1)) <= G.S_LAST, l
+            assert G.S_FIRST <= int(m.group(1)) <= G.S_LAST, l
         for m in re.finditer(r"\bs\[(\d+):(\d+)\]", l):
-            assert G.SB <= int(m.group(1)) and int(m.group(2)) <= G.S_LAST, l
+            assert G.S_FIRST <= int(m.group(1)) and int(m.group(2)) <= G.S_LAST, l
 
 
-def test_zero_registers_are_written_only_in_the_prologue():
-    """The high halves of the multiplier's addend pairs are zeroed once; no later instruction may
-    name one of them as a destination (vector loads included)."""
+def test_reduction_zeroes_its_addend_halves_itself():
+    """The high halves of the reduction stream's 64-bit addends must be zero when its multiply-adds read them, and the
+    product stream uses the same registers as scratch: every copy of the reduction starts by zeroing the eight of them,
+    and writes none of them afterwards."""
     import re
-    lines = [l for l in G.build() if not l.endswith(":")]
     zeros = {int(G.Z(j)[1:]) for j in range(8)}
-    first_loop = next(i for i, l in enumerate(G.build()) if l == ".Lzk_top:")
-    n_prologue_writes = 0
-    seen_labels = 0
-    for raw in G.build():
-        if raw.endswith(":"):
-            seen_labels += raw == ".Lzk_top:"
-            continue
+    a = G.Asm()
+    G.redc_stream(a, G.A8)
+    lines = a.lines
+    assert lines[:8] == ["v_mov_b32 %s, 0" % G.Z(j) for j in range(8)]
+    for raw in lines[8:]:
         op, _, rest = raw.partition(" ")
-        if op.startswith(("s_", "buffer_store", "ds_write")):
+        if op.startswith("s_"):
             continue
         dst = rest.split(",")[0].strip()
         regs = set()
@@ -262,10 +260,15 @@ def test_zero_registers_are_written_only_in_the_prologue():
         m = re.fullmatch(r"v\[(\d+):(\d+)\]", dst)
         if m:
             regs = set(range(int(m.group(1)), int(m.group(2)) + 1))
-        if regs & zeros:
-            assert not seen_labels and op == "v_mov_b32" and rest.endswith(", 0"), raw
-            n_prologue_writes += 1
-    assert n_prologue_writes == 8 and first_loop > 0
+        if regs & zeros:  # a multiply-add writes the pair {E, Z}: its high half is rewritten by the adds that follow...
+            assert op == "v_mad_u64_u32", raw
+    # ...so what matters is the value each multiply-add reads there: the model run below would catch a wrong one
+    rnd = random.Random(5)
+    x = rnd.randrange(F.P)
+    ops = [(F.OP_INPUT, O(F.K_NONE), O(F.K_INPUT, 0), O(F.K_NONE)), (F.OP_MUL, O(F.K_NONE), O(F.K_ACC), O(F.K_ACC)),
+           (F.OP_OUTPUT, 0, O(F.K_ACC), O(F.K_NONE)), (F.OP_OUTPUT, 1, O(F.K_ACC), O(F.K_NONE))]
+    outs, unsat, first, _ = run_lane(ops, [], [[x]], 2, 0, 0, 0)
+    assert outs == [x * x % F.P] * 2
 
 
 def test_operand_registers_are_reused_and_invalidated():
@@ -358,7 +361,7 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
             "%[xbase]": LDS_BASE + sets * n_lslots * 8192, "%[v_x]": lane * 16,
         }
         ln = IM.Lane(mem, LDS_BASE + sets * n_lslots * 8192 + n_xslots * 2048, lane, operands, set(range(G.VB, G.V_LAST + 1)),
-                     set(range(G.SB, G.S_LAST + 1)), result_operands=("%[unsat]", "%[first]"))
+                     set(range(G.S_FIRST, G.S_LAST + 1)), result_operands=("%[unsat]", "%[first]"))
         ln.lds = shared_lds
         lanes.append(ln)
         pcs.append(0)

@@ -109,13 +109,19 @@ def fullnorm29(out, x, t):
         out.append("v_add_u32 %s, %s, %s" % (x[j + 1], x[j + 1], t))
 
 
-def unpack29(out, r, w):
-    """8 words of 32 bits (w, a value below 2^256) -> 9 limbs of 29 bits (r); r and w must not overlap."""
+def unpack29(out, r, w, times32=False):
+    """8 words of 32 bits (w, a value below 2^256) -> 9 limbs of 29 bits (r); r and w must not overlap.
+    times32: the limbs of 32 times the value instead (the value must be below 2^256: the product is below 2^261)."""
+    up = 5 if times32 else 0
     for j in range(LIMBS):
-        bit = BITS * j
+        bit = BITS * j - up  # the limb is bits bit .. bit+28 of the value
+        if bit < 0:  # the lowest limb of 32 v: v shifted up, the bits below are zero
+            out.append("v_lshlrev_b32 %s, %d, %s" % (r[j], -bit, w[0]))
+            out.append("v_and_b32 %s, 0x%x, %s" % (r[j], MASK, r[j]))
+            continue
         k, s = bit // 32, bit % 32
         if j == LIMBS - 1:
-            out.append("v_lshrrev_b32 %s, %d, %s" % (r[j], s, w[k]))  # bits 232..255
+            out.append("v_lshrrev_b32 %s, %d, %s" % (r[j], s, w[k]))  # everything above (bits 232.. or 227..)
         elif s == 0:
             out.append("v_and_b32 %s, 0x%x, %s" % (r[j], MASK, w[k]))
         elif s + BITS <= 32:

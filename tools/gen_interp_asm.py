@@ -36,6 +36,9 @@ bits 8..31 of its code word; 0 there means "count the checks" (plain tapes).
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fr29  # noqa: E402
+
 P_LIMBS = [0xf0000001, 0x43e1f593, 0x79b97091, 0x2833e848, 0x8181585d, 0xb85045b6, 0xe131a029, 0x30644e72]
 R2_LIMBS = [0xae216da7, 0x1bb8e645, 0xe35c59e3, 0x53fe3ab1, 0x53bb8085, 0x8c49833d, 0x7f4e44a5, 0x0216d0b1]
 NP0 = 0xefffffff
@@ -60,11 +63,24 @@ def quad(base, half):
     return "v[%d:%d]" % (base + 4 * half, base + 4 * half + 3)
 
 
+# The product works on 9 limbs of 29 bits (tools/fr29.py) inside the registers the other streams use as scratch:
+# the 64-bit column accumulator, one temporary, both operands unpacked, the reduction multipliers (which become
+# the result), then the packed result (over the first operand) and its difference with p (over the second).
+ACCN, TT = VB, "v%d" % (VB + 2)
+UA = ["v%d" % (VB + 3 + j) for j in range(9)]
+UB = ["v%d" % (VB + 12 + j) for j in range(9)]
+M9 = ["v%d" % (VB + 21 + j) for j in range(9)]
+W8, T8 = UA[:8], UB[:8]
+assert VB + 29 <= VB + 33
+
 VA, VBB, VACC, VP = VB + 34, VB + 42, VB + 50, VB + 58
 A8, B8, ACC8, P8 = vreg8(VA), vreg8(VBB), vreg8(VACC), vreg8(VP)
 AD_A, AD_B, AD_C, FIRST, VT0, VT1 = ["v%d" % (VB + 66 + k) for k in range(6)]
 V_LAST = VB + 71
 
+S_FIRST = 38
+SP29 = ["s%d" % (S_FIRST + j) for j in range(9)]  # p as 9 limbs of 29 bits
+SNP29 = "s%d" % (S_FIRST + 9)                      # -1/p mod 2^29
 SB = 48
 D_OPS, D_CST, D_GS, D_IO = ["s[%d:%d]" % (SB + 4 * k, SB + 4 * k + 3) for k in range(4)]
 d_word = lambda k, w: "s%d" % (SB + 4 * k + w)
@@ -118,51 +134,28 @@ class Asm:
 
 # ---- arithmetic streams -----------------------------------------------------
 def mul_stream(a, x, y, r):
-    """r = x*y*2^-256 mod p; x, y, r lists of 8 registers; r may alias x or y (the results
-    are written by the last eight instructions, after every read of x and y)."""
-    def mad(dst, u, v, addend):
-        a.e("v_mad_u64_u32 %s, %s, %s, %s, %s" % (dst, CS, u, v, addend))
-    # Z(0..7), the high halves of the addend pairs, are zeroed once in the prologue and never
-    # written again by any stream
-    for i in range(8):
-        if i == 0:
-            for j in range(8):
-                mad(D(j), x[j], y[0], "0")
-        a.e("v_mov_b32 %s, %s" % (E(0), L(0)))
-        a.e("v_add_co_u32 %s, vcc, %s, %s" % (E(1), L(1), H(0)))
-        a.e("v_mul_lo_u32 %s, %s, %s" % (M, E(0), SNP0))
-        for j in range(2, 9):
-            if j < 8:
-                a.e("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (E(j), L(j), H(j - 1)))
-            else:
-                a.e("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (E(8), H(7)))
-            mad(D(j - 2), M, P8[j - 2], EZ(j - 2))
-        mad(D(7), M, P8[7], EZ(7))
-        a.e("v_add_co_u32 %s, vcc, %s, %s" % (E(0), L(1), H(0)))
-        if i < 7:
-            mad(D(0), x[0], y[i + 1], EZ(0))
-        else:
-            a.e("s_nop 0")
-        for j in range(2, 9):
-            if j < 8:
-                a.e("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (E(j - 1), L(j), H(j - 1)))
-            else:
-                a.e("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (E(7), E(8), H(7)))
-            if i < 7:
-                mad(D(j - 1), x[j - 1], y[i + 1], EZ(j - 1))
-            elif j < 8:
-                a.e("s_nop 0")
-    a.e("v_sub_co_u32 %s, vcc, %s, %s" % (L(0), E(0), P8[0]))
+    """r = x*y*2^-256 mod p, below p, for x, y below p; x, y, r lists of 8 registers; r may alias x or y.
+    The 8 x 32-bit operands are unpacked to 9 limbs of 29 bits, x as 32 x, and multiplied with the radix-2^261
+    Montgomery product of tools/fr29.py (162 multiply-adds into 64-bit column sums and no add that writes a carry:
+    on gfx950 such an add costs an issue slot like a multiply): 32 x y 2^-261 = x y 2^-256.  The result, below
+    1.3 p with limbs below 2^29, is packed back to 8 words and p is subtracted once if it fits."""
+    fr29.unpack29(a.lines, UA, x, times32=True)
+    fr29.unpack29(a.lines, UB, y)
+    fr29.mul29(a.lines, UA, UB, M9, M9, ACCN, SP29, SNP29, CS)
+    fr29.pack29(a.lines, W8, M9, TT)
+    a.e("v_sub_co_u32 %s, vcc, %s, %s" % (T8[0], W8[0], P8[0]))
     for j in range(1, 8):
         a.e("s_nop 0")
-        a.e("v_subb_co_u32 %s, vcc, %s, %s, vcc" % (L(j), E(j), P8[j]))
+        a.e("v_subb_co_u32 %s, vcc, %s, %s, vcc" % (T8[j], W8[j], P8[j]))
     a.e("s_nop 1")
-    for j in range(8):
-        a.e("v_cndmask_b32 %s, %s, %s, vcc" % (r[j], L(j), E(j)))
+    for j in range(8):  # borrow: the product was below p
+        a.e("v_cndmask_b32 %s, %s, %s, vcc" % (r[j], T8[j], W8[j]))
 
 
 def redc_stream(a, x):
     """E(0..7) = x * 2^-256 mod p for x < p."""
+    for j in range(8):  # the high halves of the addend pairs (the product stream uses these registers too)
+        a.e("v_mov_b32 %s, 0" % Z(j))
     for j in range(8):
         a.e("v_mov_b32 %s, %s" % (E(j), x[j]))
     a.e("v_mul_lo_u32 %s, %s, %s" % (M, E(0), SNP0))
@@ -347,8 +340,9 @@ def build():
         a.e("v_mov_b32 %s, 0x%08x" % (P8[j], P_LIMBS[j]))
     for j in range(8):
         a.e("v_mov_b32 %s, 0" % ACC8[j])
-    for j in range(8):
-        a.e("v_mov_b32 %s, 0" % Z(j))
+    for j in range(9):
+        a.e("s_mov_b32 %s, 0x%x" % (SP29[j], fr29.P_LIMBS[j]))
+    a.e("s_mov_b32 %s, 0x%x" % (SNP29, fr29.NP))
     a.e("v_mov_b32 %s, -1" % FIRST)
     a.e("s_mov_b32 %s, -1" % TAG_A)
     a.e("s_mov_b32 %s, -1" % TAG_B)
@@ -604,13 +598,13 @@ def build():
 
 def clobbers():
     v = ['"v%d"' % k for k in range(VB, V_LAST + 1)]
-    s = ['"s%d"' % k for k in range(SB, S_LAST + 1)]
+    s = ['"s%d"' % k for k in range(S_FIRST, S_LAST + 1)]
     return ", ".join(v + s + ['"vcc"', '"scc"', '"memory"'])
 
 
 def render(lines):
     out = ["// generated by tools/gen_interp_asm.py -- do not edit",
-           "// vector registers v%d..v%d, scalar registers s%d..s%d" % (VB, V_LAST, SB, S_LAST),
+           "// vector registers v%d..v%d, scalar registers s%d..s%d" % (VB, V_LAST, S_FIRST, S_LAST),
            "#define ZKIR_INTERP_CORE_ASM \\"]
     for l in lines:
         out.append('  "%s\\n" \\' % l)

@@ -293,7 +293,9 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
         const Fr c = load_operand(op.dst, acc, cx);
         const bool bad = live && !u256_eq(t, c);
         wave_unsat += __popcll(__ballot(bad));
-        if (bad && first_bad == 0xffffffffu) first_bad = check_k;
+        // the constraint's number: carried by the op (number + 1 in bits 8..31), else its position among the CHECK ops
+        const uint32_t id = (op.code >> 8) ? (op.code >> 8) - 1u : check_k;
+        if (bad && id < first_bad) first_bad = id;
         check_k++;
       } else if (code == ZKIR_OP_OUTPUT) {
         if (out) {  // nobody wants the outputs: skip the conversion too

@@ -72,16 +72,21 @@ inline bool check_tape(const zkir_tape_hdr& h, const void* blob, size_t bytes, s
   // number exactly once
   uint32_t barriers[ZKIR_MAX_STRANDS] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t strand = 0, strand_end = strands ? h.strand_ops[0] : h.n_ops;
-  std::vector<bool> seen_check(strands ? h.n_constraints : 0, false);
+  // CHECK ops carry their constraint number + 1 in bits 8..31 of `code`: all of them in a strand tape, all or none
+  // of them in a plain tape (none: the k-th CHECK op is constraint k)
+  std::vector<bool> seen_check;
+  uint32_t numbered = 0;
   for (uint32_t i = 0; i < h.n_ops; i++) {
     const zkir_op& op = ops[i];
     while (strands && i >= strand_end && strand + 1 < h.n_strands) strand_end += h.strand_ops[++strand];
     const uint32_t code = op.code & 0xffu;
     if (op.code & ~0xffu) {
-      if (!(strands && code == ZKIR_OP_CHECK)) return bad("reserved opcode bits set");
+      if (code != ZKIR_OP_CHECK) return bad("reserved opcode bits set");
+      if (seen_check.empty()) seen_check.assign(h.n_constraints, false);
       const uint32_t id = (op.code >> 8) - 1;
       if (id >= h.n_constraints || seen_check[id]) return bad("constraint number out of range or repeated");
       seen_check[id] = true;
+      numbered++;
     } else if (strands && code == ZKIR_OP_CHECK) {
       return bad("CHECK op of a strand tape carries no constraint number");
     }
@@ -110,6 +115,7 @@ inline bool check_tape(const zkir_tape_hdr& h, const void* blob, size_t bytes, s
     }
   }
   if (checks != h.n_constraints) return bad("n_constraints does not match the CHECK ops");
+  if (numbered && numbered != checks) return bad("some CHECK ops carry a constraint number and some do not");
   for (uint32_t s = 1; strands && s < h.n_strands; s++)
     if (barriers[s] != barriers[0]) return bad("strands hold different numbers of barriers");
   return true;

@@ -21,11 +21,13 @@ namespace zkir {
 LowerOptions default_lower_options() {
   LowerOptions o{};
   o.fold_constants = 1;
-  o.n_lslots = 4;
+  o.n_lslots = 3;  // with the victim row of the generated-stream kernel: four rows of LDS, five workgroups per CU
   o.reuse_slots = 1;
   o.max_ops = 0;
   o.bnot_variant = 0;
   o.use_acc = 1;
+  o.reorder = 1;
+  o.window_cache = 1;
   return o;
 }
 
@@ -85,6 +87,7 @@ class Pass1 {
   }
 
   std::vector<SOp> ops;
+  std::vector<uint32_t> stmt_begin;  // first op of every executed statement that is not a block (its ops stay together when the tape is reordered)
   std::vector<U256> consts;
   int32_t n_values = 0;
   size_t n_inputs = 0, n_outputs = 0;
@@ -126,6 +129,7 @@ class Pass1 {
     output_written_.assign(n_outputs, false);
     exec_block(circuit_.instructions);
     // every output element is defined: the ones nothing constrained read as 0
+    stmt_begin.push_back((uint32_t)ops.size());
     for (size_t k = 0; k < n_outputs; k++)
       if (!output_written_[k]) emit({ZKIR_OP_OUTPUT, (Ref)k, const_of(U256()), kNoRef});
   }
@@ -474,6 +478,9 @@ class Pass1 {
   }
 
   void exec(const Instruction& ins) {
+    if (ins.kind != InstrKind::If && ins.kind != InstrKind::For && ins.kind != InstrKind::While &&
+        (stmt_begin.empty() || stmt_begin.back() != ops.size()))
+      stmt_begin.push_back((uint32_t)ops.size());
     switch (ins.kind) {
       case InstrKind::VarDecl: declare(ins); return;
       case InstrKind::Assign: assign(ins); return;
@@ -543,6 +550,10 @@ struct StreamOut {
   std::vector<zkir_op> ops;
   uint32_t n_g = 0, used_l = 0, n_mul = 0;
 };
+
+StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uint32_t>& stream, int32_t nv,
+                              const std::vector<uint32_t>& check_id, bool carry_ids, const LowerOptions& opts,
+                              std::vector<uint32_t>* triples);
 
 StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>& stream, int32_t nv,
                        const std::vector<uint32_t>& xhome, const std::vector<uint32_t>& check_id, bool carry_ids,
@@ -670,6 +681,340 @@ StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>&
       if (kind == ZKIR_KIND_LSLOT) free_l.push_back(idx);
       if (kind == ZKIR_KIND_GSLOT) free_g.push_back(idx);
     }
+  }
+  return out;
+}
+
+// The same for a plain tape, with the on-chip window run as a cache whose future is known.  A value takes a window
+// slot at its definition when its next read comes sooner than that of the value it would push out (the resident whose
+// next read lies farthest away goes); it is read from the window for as long as it stays there.  A value that is
+// read again after it left the window also gets a device slot, written by a COPY op right behind its definition
+// (the accumulator still holds it).  A circuit whose values are read at random points of a long program keeps, in
+// the few slots the window has, the values about to be read, instead of only those whose every read is near.
+StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uint32_t>& stream, int32_t nv,
+                              const std::vector<uint32_t>& check_id, bool carry_ids, const LowerOptions& opts,
+                              std::vector<uint32_t>* triples) {
+  const size_t n = stream.size();
+  auto op_at = [&](size_t i) -> const SOp& { return all[stream[i]]; };
+  auto defines = [](const SOp& o) {
+    return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP && o.code != ZKIR_OP_BARRIER;
+  };
+  std::vector<int64_t> def_at(nv, -1);
+  std::vector<int64_t> next_def(n + 2, (int64_t)n);
+  for (int64_t i = (int64_t)n - 1; i >= 0; i--) next_def[i] = defines(op_at(i)) ? i : next_def[i + 1];
+  // reads of every value that the accumulator cannot serve, in stream order (compressed rows)
+  std::vector<uint32_t> n_uses(nv + 1, 0);
+  auto sources = [&](const SOp& o, Ref out[3]) {
+    out[0] = out[1] = out[2] = kNoRef;
+    if (o.code == ZKIR_OP_INPUT || o.code == ZKIR_OP_NOP || o.code == ZKIR_OP_BARRIER) return;
+    out[0] = o.a;
+    out[1] = o.b;
+    if (o.code == ZKIR_OP_CHECK) out[2] = o.dst;
+    if (out[1] == out[0]) out[1] = kNoRef;
+    if (out[2] == out[0] || out[2] == out[1]) out[2] = kNoRef;
+  };
+  for (size_t i = 0; i < n; i++)
+    if (defines(op_at(i)) && op_at(i).dst >= 0) def_at[op_at(i).dst] = (int64_t)i;
+  auto in_acc = [&](Ref r, size_t at) { return opts.use_acc && def_at[r] >= 0 && next_def[def_at[r] + 1] >= (int64_t)at; };
+  for (size_t i = 0; i < n; i++) {
+    Ref src[3];
+    sources(op_at(i), src);
+    for (Ref r : src)
+      if (r >= 0) {
+        if (def_at[r] < 0 || def_at[r] >= (int64_t)i) throw LowerError(ZKIR_LOWER_BAD_AST, "internal: value read before its definition");
+        if (!in_acc(r, i)) n_uses[r + 1]++;
+      }
+  }
+  for (int32_t v = 0; v < nv; v++) n_uses[v + 1] += n_uses[v];
+  std::vector<uint32_t> use_pos(n_uses[nv]), fill(n_uses.begin(), n_uses.end() - 1);
+  for (size_t i = 0; i < n; i++) {
+    Ref src[3];
+    sources(op_at(i), src);
+    for (Ref r : src)
+      if (r >= 0 && !in_acc(r, i)) use_pos[fill[r]++] = (uint32_t)i;
+  }
+  std::vector<uint32_t> cursor(n_uses.begin(), n_uses.end() - 1);  // per value: its first read not yet passed
+  const uint32_t kNever = UINT32_MAX;
+  auto next_use = [&](int32_t v, size_t from) -> uint32_t {  // first read at or after `from` (calls come with growing `from`)
+    uint32_t& c = cursor[v];
+    while (c < n_uses[v + 1] && use_pos[c] < from) c++;
+    return c < n_uses[v + 1] ? use_pos[c] : kNever;
+  };
+
+  // first walk: how long every value stays in the window (the last stream position it may be read there)
+  std::vector<int64_t> resident_until(nv, -1);
+  std::vector<int32_t> resident;
+  const size_t window = std::min<size_t>(opts.n_lslots, ZKIR_MAX_LSLOTS);
+  for (size_t i = 0; i < n && window; i++) {
+    const SOp& o = op_at(i);
+    if (!defines(o) || o.dst < 0) continue;
+    const int32_t v = o.dst;
+    for (size_t k = 0; k < resident.size();) {  // the dead leave
+      if (next_use(resident[k], i) == kNever) {
+        resident_until[resident[k]] = (int64_t)i - 1;
+        resident[k] = resident.back();
+        resident.pop_back();
+      } else {
+        k++;
+      }
+    }
+    const uint32_t nu = next_use(v, i + 1);
+    if (nu == kNever) continue;
+    if (resident.size() < window) {
+      resident.push_back(v);
+      continue;
+    }
+    size_t far = SIZE_MAX;
+    uint32_t far_use = nu;
+    for (size_t k = 0; k < resident.size(); k++) {
+      const uint32_t u = next_use(resident[k], i);
+      if (u > far_use && u != (uint32_t)i) {  // (a value this very op reads keeps its slot: the op's result would land on it)
+        far = k;
+        far_use = u;
+      }
+    }
+    if (far != SIZE_MAX) {
+      resident_until[resident[far]] = (int64_t)i - 1;
+      resident[far] = v;
+    }
+  }
+  for (int32_t v : resident) resident_until[v] = (int64_t)n;
+  // `resident_until[v] >= def` now means: v is in the window from its definition to that position
+
+  // second walk: slots and ops
+  std::fill(cursor.begin(), cursor.end(), 0);
+  for (int32_t v = 0; v < nv; v++) cursor[v] = n_uses[v];
+  std::vector<uint32_t> lslot(nv, UINT32_MAX), gslot(nv, UINT32_MAX);
+  std::vector<uint32_t> free_l, free_g;
+  for (uint32_t k = (uint32_t)window; k-- > 0;) free_l.push_back(k);
+  std::vector<int32_t> l_dies_head(n + 1, -1), l_dies_next(nv, -1), g_dies_head(n + 1, -1), g_dies_next(nv, -1);
+  StreamOut out;
+  out.ops.reserve(n + n / 8);
+  auto src_operand = [&](Ref r, size_t at) -> uint32_t {
+    if (r == kNoRef) return ZKIR_OPERAND_NONE;
+    if (is_const(r)) return ZKIR_OPERAND(ZKIR_KIND_CONST, const_index(r));
+    if (in_acc(r, at)) return ZKIR_OPERAND_ACC;
+    if (lslot[r] != UINT32_MAX && (int64_t)at <= resident_until[r]) return ZKIR_OPERAND(ZKIR_KIND_LSLOT, lslot[r]);
+    if (gslot[r] == UINT32_MAX) throw LowerError(ZKIR_LOWER_BAD_AST, "internal: value has no home");
+    return ZKIR_OPERAND(ZKIR_KIND_GSLOT, gslot[r]);
+  };
+  for (size_t i = 0; i < n; i++) {
+    const SOp& o = op_at(i);
+    zkir_op t{};
+    t.code = o.code;
+    bool also_device = false;
+    uint32_t device_home = 0;
+    if (o.code == ZKIR_OP_INPUT) {
+      t.a = ZKIR_OPERAND(ZKIR_KIND_INPUT, (uint32_t)o.a);
+      t.b = ZKIR_OPERAND_NONE;
+    } else {
+      t.a = src_operand(o.a, i);
+      t.b = src_operand(o.b, i);
+    }
+    if ((o.code == ZKIR_OP_MUL || o.code == ZKIR_OP_ADD || o.code == ZKIR_OP_CHECK) &&
+        (t.b >> ZKIR_KIND_SHIFT) == ZKIR_KIND_ACC && (t.a >> ZKIR_KIND_SHIFT) != ZKIR_KIND_ACC)
+      std::swap(t.a, t.b);
+    if (o.code == ZKIR_OP_OUTPUT) {
+      t.dst = (uint32_t)o.dst;
+    } else if (o.code == ZKIR_OP_CHECK) {
+      t.dst = src_operand(o.dst, i);
+      const uint32_t id = check_id[stream[i]];
+      if (carry_ids) t.code |= (id + 1) << 8;
+      if (triples) {
+        (*triples)[3 * (size_t)id] = t.a;
+        (*triples)[3 * (size_t)id + 1] = t.b;
+        (*triples)[3 * (size_t)id + 2] = t.dst;
+      }
+    } else if (o.code == ZKIR_OP_NOP || o.code == ZKIR_OP_BARRIER) {
+      t.dst = t.a = t.b = ZKIR_OPERAND_NONE;
+    } else {
+      if (o.code == ZKIR_OP_MUL) out.n_mul++;
+      const int32_t v = o.dst;
+      const uint32_t first = n_uses[v], end = n_uses[v + 1];  // its reads beyond the accumulator's reach
+      t.dst = ZKIR_OPERAND_NONE;
+      if (first < end) {
+        const int64_t until = resident_until[v];
+        uint32_t last_in_window = UINT32_MAX, n_after = 0;
+        for (uint32_t c = first; c < end; c++) {
+          if ((int64_t)use_pos[c] <= until) last_in_window = use_pos[c];
+          else n_after++;
+        }
+        const uint32_t last = use_pos[end - 1];
+        if (last_in_window != UINT32_MAX) {
+          if (free_l.empty()) throw LowerError(ZKIR_LOWER_BAD_AST, "internal: window slot accounting");
+          lslot[v] = free_l.back();
+          free_l.pop_back();
+          out.used_l = std::max(out.used_l, lslot[v] + 1);
+          t.dst = ZKIR_OPERAND(ZKIR_KIND_LSLOT, lslot[v]);
+          // the slot is free again once the value has left the window: after its last read there, or when its
+          // successor arrives (position until + 1 defines it), whichever the first walk decided
+          const size_t release = (size_t)std::min<int64_t>(until, (int64_t)n - 1);
+          l_dies_next[v] = l_dies_head[release];
+          l_dies_head[release] = v;
+        }
+        if (n_after || last_in_window == UINT32_MAX) {
+          uint32_t g;
+          if (!free_g.empty() && opts.reuse_slots) {
+            g = free_g.back();
+            free_g.pop_back();
+          } else {
+            g = out.n_g++;
+          }
+          gslot[v] = g;
+          if (last_in_window == UINT32_MAX) {
+            t.dst = ZKIR_OPERAND(ZKIR_KIND_GSLOT, g);
+          } else {
+            also_device = true;
+            device_home = ZKIR_OPERAND(ZKIR_KIND_GSLOT, g);
+          }
+          if (opts.reuse_slots) {
+            g_dies_next[v] = g_dies_head[last];
+            g_dies_head[last] = v;
+          }
+        }
+      }
+    }
+    out.ops.push_back(t);
+    if (also_device) out.ops.push_back(zkir_op{ZKIR_OP_COPY, device_home, ZKIR_OPERAND_ACC, ZKIR_OPERAND_NONE});
+    for (int32_t v = l_dies_head[i]; v >= 0; v = l_dies_next[v]) free_l.push_back(lslot[v]);
+    for (int32_t v = g_dies_head[i]; v >= 0; v = g_dies_next[v]) free_g.push_back(gslot[v]);
+  }
+  return out;
+}
+
+// ---- the order of the statements of a plain tape ----
+// The ops of one statement stay together and in order; the statements themselves may run in any order that defines
+// every value before it is read (ops are pure, single assignment).  A circuit whose constraints read earlier signals
+// at random leaves that freedom wide open, and the device-memory traffic of its tape depends on it: a statement that
+// reads what the operand registers, the victim row or the window still hold loads nothing for it.  Greedy: after
+// each statement, among the ready statements that read one of the values the last statements read or defined, take
+// the one that reads most of them (a value read for the last time counts more: it then never needs a device slot);
+// with no such statement, the earliest ready one in program order.
+std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std::vector<uint32_t>& stmt_begin, int32_t nv) {
+  const size_t n = ops.size();
+  std::vector<uint32_t> begin;
+  for (uint32_t b : stmt_begin)
+    if (b < n && (begin.empty() || b > begin.back())) begin.push_back(b);
+  if (begin.empty() || begin[0] != 0) begin.insert(begin.begin(), 0u);
+  const size_t nb = begin.size();
+  begin.push_back((uint32_t)n);
+  std::vector<uint32_t> order(n);
+  for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+  if (nb < 3) return order;
+  auto defines = [](const SOp& o) { return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP; };
+  std::vector<int32_t> def_stmt(nv, -1);
+  for (size_t b = 0; b < nb; b++)
+    for (uint32_t i = begin[b]; i < begin[b + 1]; i++)
+      if (defines(ops[i]) && ops[i].dst >= 0) def_stmt[ops[i].dst] = (int32_t)b;
+  // values a statement reads that another statement defines (at most a few), and who reads each value
+  std::vector<uint32_t> ext_begin(nb + 1, 0), ext;
+  std::vector<uint32_t> n_readers(nv, 0), n_wait(nb, 0);
+  for (size_t b = 0; b < nb; b++) {
+    ext_begin[b] = (uint32_t)ext.size();
+    for (uint32_t i = begin[b]; i < begin[b + 1]; i++) {
+      const SOp& o = ops[i];
+      if (o.code == ZKIR_OP_INPUT || o.code == ZKIR_OP_NOP) continue;
+      const Ref src[3] = {o.b, o.a, o.code == ZKIR_OP_CHECK ? o.dst : kNoRef};
+      for (Ref r : src) {
+        if (r < 0 || def_stmt[r] < 0 || def_stmt[r] == (int32_t)b) continue;
+        bool seen = false;
+        for (uint32_t q = ext_begin[b]; q < ext.size(); q++) seen = seen || ext[q] == (uint32_t)r;
+        if (!seen) ext.push_back((uint32_t)r);
+      }
+    }
+  }
+  ext_begin[nb] = (uint32_t)ext.size();
+  std::vector<uint32_t> readers_begin(nv + 1, 0);
+  for (uint32_t r : ext) readers_begin[r + 1]++;
+  for (int32_t v = 0; v < nv; v++) readers_begin[v + 1] += readers_begin[v];
+  std::vector<uint32_t> readers(ext.size()), rfill(readers_begin.begin(), readers_begin.end() - 1);
+  std::vector<uint32_t> succ_begin(nb + 1, 0);
+  for (size_t b = 0; b < nb; b++) {
+    // distinct defining statements this one waits for
+    for (uint32_t q = ext_begin[b]; q < ext_begin[b + 1]; q++) {
+      readers[rfill[ext[q]]++] = (uint32_t)b;
+      n_readers[ext[q]]++;
+      bool seen = false;
+      for (uint32_t p = ext_begin[b]; p < q; p++) seen = seen || def_stmt[ext[p]] == def_stmt[ext[q]];
+      if (!seen) {
+        n_wait[b]++;
+        succ_begin[(size_t)def_stmt[ext[q]] + 1]++;
+      }
+    }
+  }
+  for (size_t b = 0; b < nb; b++) succ_begin[b + 1] += succ_begin[b];
+  std::vector<uint32_t> succ(succ_begin[nb]), sfill(succ_begin.begin(), succ_begin.end() - 1);
+  for (size_t b = 0; b < nb; b++)
+    for (uint32_t q = ext_begin[b]; q < ext_begin[b + 1]; q++) {
+      bool seen = false;
+      for (uint32_t p = ext_begin[b]; p < q; p++) seen = seen || def_stmt[ext[p]] == def_stmt[ext[q]];
+      if (!seen) succ[sfill[def_stmt[ext[q]]]++] = (uint32_t)b;
+    }
+
+  std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> ready;  // earliest first
+  std::vector<uint8_t> state(nb, 0);  // 0 waiting, 1 ready, 2 done
+  for (size_t b = 0; b < nb; b++)
+    if (n_wait[b] == 0) {
+      ready.push((uint32_t)b);
+      state[b] = 1;
+    }
+  // the values within reach: what the last statement read (operand registers, victim row) and what the last few
+  // statements defined (still cheap to keep in the window)
+  const size_t kRecent = 30;
+  std::vector<uint32_t> recent;  // ring of value ids
+  size_t recent_at = 0;
+  std::vector<uint32_t> last_read;
+  std::vector<uint32_t> stamp(nv, 0), score_stamp(nb, 0);
+  std::vector<float> score(nb, 0.f);
+  uint32_t round = 0;
+  std::vector<uint32_t> out;
+  out.reserve(n);
+  std::vector<uint32_t> touched;
+  for (size_t placed = 0; placed < nb; placed++) {
+    round++;
+    // candidates: ready readers of the values within reach
+    touched.clear();
+    auto consider = [&](uint32_t v, float weight) {
+      if (stamp[v] == round) return;
+      stamp[v] = round;
+      const bool closes = n_readers[v] == 1;  // its last reader: the value then never leaves the chip
+      for (uint32_t q = readers_begin[v]; q < readers_begin[v + 1]; q++) {
+        const uint32_t b = readers[q];
+        if (state[b] != 1) continue;
+        if (score_stamp[b] != round) {
+          score_stamp[b] = round;
+          score[b] = 0.f;
+          touched.push_back(b);
+        }
+        score[b] += weight + (closes ? 2.f : 0.f);
+      }
+    };
+    for (uint32_t v : last_read) consider(v, 4.f);  // (3 for the registers and the row, 1 more below when it is recent too)
+    for (uint32_t v : recent) consider(v, 1.f);
+    uint32_t best = UINT32_MAX;
+    for (uint32_t b : touched)
+      if (best == UINT32_MAX || score[b] > score[best] || (score[b] == score[best] && b < best)) best = b;
+    if (best == UINT32_MAX) {
+      while (!ready.empty() && state[ready.top()] != 1) ready.pop();
+      if (ready.empty()) throw LowerError(ZKIR_LOWER_BAD_AST, "internal: statement scheduling made no progress");
+      best = ready.top();
+      ready.pop();
+    }
+    state[best] = 2;
+    for (uint32_t i = begin[best]; i < begin[best + 1]; i++) {
+      out.push_back(i);
+      if (defines(ops[i]) && ops[i].dst >= 0) {
+        if (recent.size() < kRecent) recent.push_back((uint32_t)ops[i].dst);
+        else recent[recent_at++ % kRecent] = (uint32_t)ops[i].dst;
+      }
+    }
+    last_read.assign(ext.begin() + ext_begin[best], ext.begin() + std::min<size_t>(ext_begin[best] + 3, ext_begin[best + 1]));
+    for (uint32_t q = ext_begin[best]; q < ext_begin[best + 1]; q++) n_readers[ext[q]]--;
+    for (uint32_t q = succ_begin[best]; q < succ_begin[best + 1]; q++)
+      if (--n_wait[succ[q]] == 0) {
+        state[succ[q]] = 1;
+        ready.push(succ[q]);
+      }
   }
   return out;
 }
@@ -1080,8 +1425,11 @@ Tape Lowerer::lower() {
 
   std::vector<uint32_t> stream(n);
   for (size_t i = 0; i < n; i++) stream[i] = (uint32_t)i;
-  StreamOut so = place_stream(ops, stream, nv, {}, check_id, false, opts_, &triples);
-  h.n_ops = (uint32_t)n;
+  const bool reorder = opts_.reorder && n_checks < (1u << 24) - 1;
+  if (reorder) stream = schedule_statements(ops, p1.stmt_begin, nv);
+  StreamOut so = opts_.window_cache ? place_stream_cached(ops, stream, nv, check_id, reorder, opts_, &triples)
+                                    : place_stream(ops, stream, nv, {}, check_id, reorder, opts_, &triples);
+  h.n_ops = (uint32_t)so.ops.size();
   h.n_gslots = so.n_g;
   h.n_lslots = so.used_l;
   h.n_mul_ops = so.n_mul;
