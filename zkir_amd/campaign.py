@@ -48,6 +48,11 @@ def lower_parallel(circuit_ids, base_seed, workers=8, window=64, lower_options=N
     that may already hold a GPU context)."""
     import queue
     import threading
+    if lower_options is None:
+        # a campaign is bound by the host side (generate + lower cost a few ms per circuit, its evaluation some tens of
+        # microseconds), so lower skips the search for the statement order with the least device-memory traffic
+        lower_options = api.default_lower_options()
+        lower_options.reorder = 0
     ids = list(circuit_ids)
     step = max(1, window * workers)
     batches = queue.Queue(maxsize=2)

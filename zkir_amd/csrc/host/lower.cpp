@@ -882,6 +882,58 @@ StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uin
   return out;
 }
 
+// Device-slot reads and writes of a tape per input vector, as the generated-stream kernels perform them: their operand
+// registers remember which operand word they hold (a and b), a device-slot value pushed out of them waits in one
+// victim row of LDS, a store to a slot makes every copy of it stale (zkir_interp_lean_kernel, tools/gen_interp_asm.py).
+uint64_t device_slot_traffic(const std::vector<zkir_op>& ops) {
+  uint32_t tag_a = UINT32_MAX, tag_b = UINT32_MAX, tag_v = UINT32_MAX;
+  uint64_t n = 0;
+  auto fetch = [&](uint32_t word, uint32_t* tag) {
+    const uint32_t kind = word >> ZKIR_KIND_SHIFT;
+    if (tag && word == *tag) return;
+    if (tag && word == tag_v) {
+      *tag = word;
+      return;
+    }
+    if (kind == ZKIR_KIND_ACC) {
+      if (tag == &tag_b) *tag = UINT32_MAX;
+      return;
+    }
+    if (tag && (*tag >> ZKIR_KIND_SHIFT) == ZKIR_KIND_GSLOT) tag_v = *tag;
+    if (kind == ZKIR_KIND_GSLOT) n++;
+    if (tag) *tag = (kind == ZKIR_KIND_GSLOT || kind == ZKIR_KIND_LSLOT || kind == ZKIR_KIND_CONST) ? word : UINT32_MAX;
+  };
+  for (const zkir_op& op : ops) {
+    const uint32_t code = op.code & 0xffu;
+    if (code == ZKIR_OP_NOP || code == ZKIR_OP_BARRIER) continue;
+    if (code == ZKIR_OP_INPUT) {
+      tag_a = tag_b = UINT32_MAX;
+    } else if (code == ZKIR_OP_OUTPUT) {
+      fetch(op.a, &tag_a);
+      continue;
+    } else if (code == ZKIR_OP_COPY) {
+      fetch(op.a, nullptr);
+    } else if (code == ZKIR_OP_NEG) {
+      fetch(op.a, &tag_b);
+      tag_a = UINT32_MAX;
+    } else if (code == ZKIR_OP_CHECK) {
+      fetch(op.b, &tag_b);
+      fetch(op.a, &tag_a);
+      tag_a = UINT32_MAX;
+      fetch(op.dst, &tag_b);
+      continue;
+    } else {
+      fetch(op.b, &tag_b);
+      fetch(op.a, &tag_a);
+    }
+    if (tag_a == op.dst) tag_a = UINT32_MAX;
+    if (tag_b == op.dst) tag_b = UINT32_MAX;
+    if (tag_v == op.dst) tag_v = UINT32_MAX;
+    if ((op.dst >> ZKIR_KIND_SHIFT) == ZKIR_KIND_GSLOT) n++;
+  }
+  return n;
+}
+
 // ---- the order of the statements of a plain tape ----
 // The ops of one statement stay together and in order; the statements themselves may run in any order that defines
 // every value before it is read (ops are pure, single assignment).  A circuit whose constraints read earlier signals
@@ -890,7 +942,8 @@ StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uin
 // each statement, among the ready statements that read one of the values the last statements read or defined, take
 // the one that reads most of them (a value read for the last time counts more: it then never needs a device slot);
 // with no such statement, the earliest ready one in program order.
-std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std::vector<uint32_t>& stmt_begin, int32_t nv) {
+std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std::vector<uint32_t>& stmt_begin, int32_t nv,
+                                          size_t lookahead) {
   const size_t n = ops.size();
   std::vector<uint32_t> begin;
   for (uint32_t b : stmt_begin)
@@ -970,8 +1023,13 @@ std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std
   std::vector<uint32_t> out;
   out.reserve(n);
   std::vector<uint32_t> touched;
+  // A statement may run ahead of program order by a bounded number of statements only: every statement that is passed
+  // over keeps its operands alive for longer, and a circuit whose values die young in program order must not be
+  // turned into one that spills.
+  size_t earliest = 0;  // the first statement not yet placed
   for (size_t placed = 0; placed < nb; placed++) {
     round++;
+    while (earliest < nb && state[earliest] == 2) earliest++;
     // candidates: ready readers of the values within reach
     touched.clear();
     auto consider = [&](uint32_t v, float weight) {
@@ -980,7 +1038,7 @@ std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std
       const bool closes = n_readers[v] == 1;  // its last reader: the value then never leaves the chip
       for (uint32_t q = readers_begin[v]; q < readers_begin[v + 1]; q++) {
         const uint32_t b = readers[q];
-        if (state[b] != 1) continue;
+        if (state[b] != 1 || b - earliest > lookahead) continue;
         if (score_stamp[b] != round) {
           score_stamp[b] = round;
           score[b] = 0.f;
@@ -1425,10 +1483,27 @@ Tape Lowerer::lower() {
 
   std::vector<uint32_t> stream(n);
   for (size_t i = 0; i < n; i++) stream[i] = (uint32_t)i;
-  const bool reorder = opts_.reorder && n_checks < (1u << 24) - 1;
-  if (reorder) stream = schedule_statements(ops, p1.stmt_begin, nv);
-  StreamOut so = opts_.window_cache ? place_stream_cached(ops, stream, nv, check_id, reorder, opts_, &triples)
-                                    : place_stream(ops, stream, nv, {}, check_id, reorder, opts_, &triples);
+  // Program order, and (reorder) two reorderings: statements running ahead by at most 16 statements, and by any
+  // number.  Which order moves the fewest values through device memory depends on the circuit (a chain is best left
+  // alone, a circuit that reads its signals at random gains most from the widest choice): the kernel's operand
+  // cache is modelled on each tape and the cheapest is kept.
+  const bool reorder = opts_.reorder && n_checks < (1u << 24) - 1 && p1.stmt_begin.size() > 2;
+  StreamOut so;
+  uint64_t best_cost = UINT64_MAX;
+  std::vector<uint32_t> best_triples;
+  const size_t lookaheads[3] = {0, 16, SIZE_MAX};
+  for (int k = 0; k < (reorder ? 3 : 1); k++) {
+    if (k) stream = schedule_statements(ops, p1.stmt_begin, nv, lookaheads[k]);
+    StreamOut cand = opts_.window_cache ? place_stream_cached(ops, stream, nv, check_id, reorder, opts_, &triples)
+                                        : place_stream(ops, stream, nv, {}, check_id, reorder, opts_, &triples);
+    const uint64_t cost = device_slot_traffic(cand.ops) * 4096ull + std::min<uint32_t>(cand.n_g, 4095u);
+    if (cost < best_cost) {
+      best_cost = cost;
+      so = std::move(cand);
+      best_triples = triples;
+    }
+  }
+  triples.swap(best_triples);
   h.n_ops = (uint32_t)so.ops.size();
   h.n_gslots = so.n_g;
   h.n_lslots = so.used_l;
