@@ -13,7 +13,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_int32, c_size_t, c_uint
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libzkir_hip.so")
+LIB_PATH = os.environ.get("ZKIR_LIB") or os.path.join(HERE, "libzkir_hip.so")  # ZKIR_LIB: another build of the library (A/B measurements)
 
 OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_LOWER, E_BUFSIZE, E_LIMIT, E_INTERNAL, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 LOWER_CLASSES = {0: "OK", 1: "DoubleAssign", 2: "OOBIndex", 3: "DivByZero", 4: "NonQuadratic", 5: "LoopCap",

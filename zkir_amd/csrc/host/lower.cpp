@@ -21,7 +21,7 @@ namespace zkir {
 LowerOptions default_lower_options() {
   LowerOptions o{};
   o.fold_constants = 1;
-  o.n_lslots = 3;  // with the victim row of the generated-stream kernel: four rows of LDS, five workgroups per CU
+  o.n_lslots = 2;  // with the victim row of the generated-stream kernel: three rows of LDS, and five workgroups fit a CU
   o.reuse_slots = 1;
   o.max_ops = 0;
   o.bnot_variant = 0;
