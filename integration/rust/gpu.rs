@@ -22,13 +22,15 @@ pub struct TapeHdr {
 }
 
 /// zkir_lower_options of the header; `LowerOptions::default()` is NOT the library's default:
-/// fill it with zkir_lower_options_default, then set `strands = 4` to ask for a strand tape
-/// (four wavefronts per 64 vectors; circuits it does not fit come back as plain tapes).
+/// fill it with zkir_lower_options_default, then set `strands = 4` (or 8, for batches up to 2^14 vectors) to ask
+/// for a strand tape (that many wavefronts per 64 vectors; circuits it does not fit come back as plain tapes);
+/// a campaign, bound by the host side, sets `reorder = 0`.
 #[repr(C)]
 #[derive(Default, Clone, Copy)]
 pub struct LowerOptions {
     pub fold_constants: u32, pub n_lslots: u32, pub reuse_slots: u32, pub max_ops: u32, pub bnot_variant: u32,
     pub use_acc: u32, pub max_iterations: u32, pub window_lifetime: u32, pub strands: u32, pub max_xslots: u32,
+    pub reorder: u32, pub window_cache: u32,
 }
 
 #[link(name = "zkir_hip")]
@@ -38,6 +40,9 @@ extern "C" {
     fn zkir_circuit_free(c: *mut c_void);
     fn zkir_lower_options_default(o: *mut LowerOptions) -> i32;
     fn zkir_lower(c: *const c_void, opts: *const LowerOptions, out: *mut *mut c_void, class: *mut i32) -> i32;
+    /// generate + lower for a batch of circuits on the library's own host threads (cfgs: *const zkir_generator_config or null)
+    fn zkir_generate_lower_many(seeds: *const u64, cfgs: *const c_void, n: u32, opts: *const LowerOptions, threads: u32,
+                                tapes: *mut *mut c_void, classes: *mut i32) -> i32;
     fn zkir_tape_header(t: *const c_void, hdr: *mut TapeHdr) -> i32;
     fn zkir_tape_blob(t: *const c_void, blob: *mut *const c_void, bytes: *mut usize) -> i32;
     fn zkir_tape_free(t: *mut c_void);

@@ -23,7 +23,11 @@ def main():
     dev = torch.device("cuda:0")
     ctx = z.Context(0)
     t0 = time.time()
-    tapes = [t for _, cls, t in campaign.lower_parallel(range(n_circuits), 7, workers=16) if t is not None]
+    # the tapes run many times here, so lower may search for the statement order with the least device-memory traffic
+    # (ZKIR_MEASURE_REORDER=0: program order, as a campaign lowers them)
+    options = z.default_lower_options()
+    options.reorder = int(os.environ.get("ZKIR_MEASURE_REORDER", "1"))
+    tapes = [t for _, cls, t in campaign.lower_parallel(range(n_circuits), 7, workers=16, lower_options=options) if t is not None]
     # longest tapes first: the work queue hands items out in order, so the tail is made of short ones
     tapes.sort(key=lambda t: -t.hdr.n_ops)
     host_s = time.time() - t0
@@ -52,7 +56,8 @@ def main():
     print(json.dumps({"config": "3: %d distinct circuits (%d lowered OK, %d..%d constraints) x %d vectors" % (
         n_circuits, len(tapes), min(t.hdr.n_constraints for t in tapes), max(t.hdr.n_constraints for t in tapes), n_vec),
         "gpu_ms": 1e3 * dt, "checks_per_s": checks / dt, "fr_mul_per_s": muls / dt, "unsat": int(unsat.sum()),
-        "host_generate_lower_s_16_threads": host_s}))
+        "host_generate_lower_s_16_threads": host_s, "reorder": options.reorder,
+        "mulhi_frac": 128.0 * muls / dt / ctx.int_mul_rate(0)}))
 
 
 if __name__ == "__main__":
