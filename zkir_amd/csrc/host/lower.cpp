@@ -1013,11 +1013,14 @@ std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std
     }
   // the values within reach: what the last statement read (operand registers, victim row) and what the last few
   // statements defined (still cheap to keep in the window)
-  const size_t kRecent = 30;
+  // weights found by a search over generated circuits of the benchmark's kind (five seeds): reading the last reader's
+  // operands counts little, closing a value defined among the last 16 counts most
+  const size_t kRecent = 16;
+  const float w_cache = 0.5f, w_recent = 1.f, w_last = 16.f;
   std::vector<uint32_t> recent;  // ring of value ids
   size_t recent_at = 0;
   std::vector<uint32_t> last_read;
-  std::vector<uint32_t> stamp(nv, 0), score_stamp(nb, 0);
+  std::vector<uint32_t> stamp(nv, 0), in_recent(nv, 0), score_stamp(nb, 0);
   std::vector<float> score(nb, 0.f);
   uint32_t round = 0;
   std::vector<uint32_t> out;
@@ -1032,10 +1035,10 @@ std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std
     while (earliest < nb && state[earliest] == 2) earliest++;
     // candidates: ready readers of the values within reach
     touched.clear();
-    auto consider = [&](uint32_t v, float weight) {
+    auto consider = [&](uint32_t v, float weight, bool is_recent) {
       if (stamp[v] == round) return;
       stamp[v] = round;
-      const bool closes = n_readers[v] == 1;  // its last reader: the value then never leaves the chip
+      const bool closes = is_recent && n_readers[v] == 1;  // its last reader: the value then never leaves the chip
       for (uint32_t q = readers_begin[v]; q < readers_begin[v + 1]; q++) {
         const uint32_t b = readers[q];
         if (state[b] != 1 || b - earliest > lookahead) continue;
@@ -1044,11 +1047,12 @@ std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std
           score[b] = 0.f;
           touched.push_back(b);
         }
-        score[b] += weight + (closes ? 2.f : 0.f);
+        score[b] += weight + (closes ? w_last : 0.f);
       }
     };
-    for (uint32_t v : last_read) consider(v, 4.f);  // (3 for the registers and the row, 1 more below when it is recent too)
-    for (uint32_t v : recent) consider(v, 1.f);
+    for (uint32_t v : recent) in_recent[v] = round;
+    for (uint32_t v : last_read) consider(v, w_cache + (in_recent[v] == round ? w_recent : 0.f), in_recent[v] == round);
+    for (uint32_t v : recent) consider(v, w_recent, true);
     uint32_t best = UINT32_MAX;
     for (uint32_t b : touched)
       if (best == UINT32_MAX || score[b] > score[best] || (score[b] == score[best] && b < best)) best = b;
