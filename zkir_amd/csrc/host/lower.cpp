@@ -62,7 +62,12 @@ struct Val {
   U256 value;             // when known
   Ref ref = kNoRef;       // where the tape holds it (may be absent for a folded known value)
   Degree deg = kKnown;
-  // deg == kQuadratic: value = scale * qa * qb + sum(terms)
+  int32_t quad = -1;      // deg == kQuadratic: which entry of Pass1::quads_ describes it
+};
+
+// a quadratic value: scale * qa * qb + sum(terms).  Kept beside the values (one per product of two linear values and
+// per sum built on it), so that a Val is plain data: expression evaluation copies one per node.
+struct Quad {
   Ref qa = kNoRef, qb = kNoRef;
   U256 scale;
   std::vector<Term> terms;
@@ -275,20 +280,19 @@ class Pass1 {
         Val& q = da == kQuadratic ? a : b;
         Val& l = da == kQuadratic ? b : a;
         r->deg = kQuadratic;
-        r->qa = q.qa;
-        r->qb = q.qb;
-        r->scale = q.scale;
-        r->terms = q.terms;
+        Quad nq = quads_[(size_t)q.quad];
         std::vector<Term> lt = as_terms(l);
         if (k == ExprKind::Sub) {
           if (&q == &b) {  // l - q: negate the quadratic part
-            r->scale = fr::neg(r->scale);
-            for (Term& t : r->terms) t.coef = fr::neg(t.coef);
+            nq.scale = fr::neg(nq.scale);
+            for (Term& t : nq.terms) t.coef = fr::neg(t.coef);
           } else {  // q - l
             for (Term& t : lt) t.coef = fr::neg(t.coef);
           }
         }
-        r->terms.insert(r->terms.end(), lt.begin(), lt.end());
+        nq.terms.insert(nq.terms.end(), lt.begin(), lt.end());
+        r->quad = (int32_t)quads_.size();
+        quads_.push_back(std::move(nq));
       }
     } else if (k == ExprKind::Mul) {
       if (da == kKnown || db == kKnown) {
@@ -298,17 +302,20 @@ class Pass1 {
           r->deg = ot.deg;  // known * linear stays linear
         } else if (ot.deg == kQuadratic) {
           r->deg = kQuadratic;
-          r->qa = ot.qa;
-          r->qb = ot.qb;
-          r->scale = fr::mul(ot.scale, kn.value);
-          r->terms = ot.terms;
-          for (Term& t : r->terms) t.coef = fr::mul(t.coef, kn.value);
+          Quad nq = quads_[(size_t)ot.quad];
+          nq.scale = fr::mul(nq.scale, kn.value);
+          for (Term& t : nq.terms) t.coef = fr::mul(t.coef, kn.value);
+          r->quad = (int32_t)quads_.size();
+          quads_.push_back(std::move(nq));
         }
       } else if (da == kLinear && db == kLinear) {
         r->deg = kQuadratic;
-        r->qa = ref_of(a);
-        r->qb = ref_of(b);
-        r->scale = U256::from_u64(1);
+        Quad nq;
+        nq.qa = ref_of(a);
+        nq.qb = ref_of(b);
+        nq.scale = U256::from_u64(1);
+        r->quad = (int32_t)quads_.size();
+        quads_.push_back(std::move(nq));
       }
     } else if (k == ExprKind::Div && db == kKnown) {
       // division by a known non-zero value is multiplication by its inverse
@@ -318,11 +325,11 @@ class Pass1 {
         r->deg = da;
       } else if (da == kQuadratic) {
         r->deg = kQuadratic;
-        r->qa = a.qa;
-        r->qb = a.qb;
-        r->scale = fr::mul(a.scale, inv);
-        r->terms = a.terms;
-        for (Term& t : r->terms) t.coef = fr::mul(t.coef, inv);
+        Quad nq = quads_[(size_t)a.quad];
+        nq.scale = fr::mul(nq.scale, inv);
+        for (Term& t : nq.terms) t.coef = fr::mul(t.coef, inv);
+        r->quad = (int32_t)quads_.size();
+        quads_.push_back(std::move(nq));
       }
     }
     if (r->deg == kKnown) r->deg = kLinear;  // not known: at least one operand depends on a signal
@@ -452,11 +459,12 @@ class Pass1 {
     output_written_[out_index] = true;
     const Ref one = const_of(U256::from_u64(1));
     if (v.deg == kQuadratic) {
-      Ref A = v.qa;
-      if (!(v.scale == U256::from_u64(1))) A = new_value(ZKIR_OP_MUL, const_of(v.scale), A);
-      const Ref lin = materialize_terms(v.terms);
+      const Quad Q = quads_[(size_t)v.quad];  // (a copy: the ops emitted below do not touch quads_, but cheap enough to not depend on it)
+      Ref A = Q.qa;
+      if (!(Q.scale == U256::from_u64(1))) A = new_value(ZKIR_OP_MUL, const_of(Q.scale), A);
+      const Ref lin = materialize_terms(Q.terms);
       const Ref C = lin == kNoRef ? out : new_value(ZKIR_OP_SUB, out, lin);
-      emit({ZKIR_OP_CHECK, C, A, v.qb});
+      emit({ZKIR_OP_CHECK, C, A, Q.qb});
     } else {
       emit({ZKIR_OP_CHECK, out, out, one});  // value * 1 == signal
     }
@@ -528,6 +536,7 @@ class Pass1 {
   uint64_t max_iterations_;
   std::vector<Cells> cells_;  // one per circuit variable, in declaration order
   std::vector<Val> vals_;     // the elements of every declared variable
+  std::vector<Quad> quads_;   // what Val::quad points to
   std::vector<int32_t> pos_of_id_;
   std::unordered_map<size_t, uint32_t> pos_of_sparse_id_;
   bool dense_ids_ = true;
