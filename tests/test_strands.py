@@ -181,6 +181,11 @@ def test_lowering_into_strands_keeps_every_result(n_strands):
             assert n_bar % n_strands == 0 and len(ops) - n_bar == z.Lowerer(circuit, in_order).lower().hdr.n_ops, name
             assert (st.hdr.n_constraints, st.hdr.n_mul_ops) == (plain.hdr.n_constraints, plain.hdr.n_mul_ops)
             assert st.hdr.n_xslots <= (32 if n_strands == 4 else 48)
+            # whatever window the caller asks for, no mix of strand tapes in one launch may exceed a CU's LDS (the
+            # launch takes the most rows and the most exchange slots among its tapes; 9 KiB rows in the 29-bit kernel)
+            greedy = z.Lowerer(circuit, _strand_options(strands=n_strands, n_lslots=16)).lower().hdr
+            assert 2048 + (2 if n_strands == 8 else 1) * max(greedy.n_lslots, 4 if n_strands == 4 else 2) * 9216 \
+                + (32 if n_strands == 4 else 48) * 2304 + 16 <= 160 * 1024 and greedy.n_lslots <= (4 if n_strands == 4 else 2)
             if n_strands == 8:  # strands 4..7 hold only what defines nothing
                 tail = ops[sum(list(st.hdr.strand_ops)[:4]):]
                 assert all(o[0] & 0xFF in (F.OP_OUTPUT, F.OP_CHECK, F.OP_BARRIER) for o in tail), name

@@ -1475,6 +1475,9 @@ Tape Lowerer::lower() {
       const uint32_t x_bytes = (uint32_t)slot_free_from.size() * 2048u, budget = (S == 8 ? 96u : 32u) * 1024u;
       const uint32_t row_bytes = 8192u * (S == 8 ? 2u : 1u);
       sopts.n_lslots = std::min<uint32_t>(opts_.n_lslots, x_bytes >= budget ? 0u : (budget - x_bytes) / row_bytes);
+      // (a launch sizes its LDS for the most window rows and the most exchange slots among its tapes: two rows at most
+      // with eight strands, so that no mix of such tapes exceeds a CU's 160 KiB even in the 29-bit kernel's 9 KiB rows)
+      if (S == (int)ZKIR_MAX_STRANDS) sopts.n_lslots = std::min<uint32_t>(sopts.n_lslots, 2u);
       for (int s = 0; s < S; s++) {
         for (; at_epoch[s] < pl.n_epochs - 1; at_epoch[s]++) stream[s].push_back(barrier_at);
         StreamOut so = place_stream(all, stream[s], nv, xhome, check_id, true, sopts, &triples);
