@@ -132,6 +132,26 @@ def test_hand_written_strand_tape_on_the_gpu():
         ctx.close()
 
 
+@pytest.mark.gpu
+def test_a_launch_beyond_the_lds_of_a_cu_is_refused_with_a_message():
+    """A hand-written eight-strand tape that declares 16 window rows and 48 exchange slots would need 397 KiB of LDS
+    per workgroup: the evaluation call returns ZKIR_E_LIMIT and says why, nothing is launched."""
+    s = [[(F.OP_INPUT, X(k % 2), I(k % 2), NONE), BAR, (F.OP_OUTPUT, k % 4, X(0), NONE)] if k < 2 else
+         [BAR, (F.OP_OUTPUT, k % 4, X(1), NONE)] for k in range(8)]
+    hdr, blob = strand_tape(s, [7], 2, 4, 1, 16, 48)
+    tape = z.Tape.from_parts(hdr, blob)  # the format allows it
+    ctx = z.Context(0)
+    try:
+        tid = ctx.upload(tape)
+        inp = z.pack_inputs([[3, 4]] * 5, 2)
+        with pytest.raises(z.ZkirError) as e:
+            ctx.eval_batch(tid, inp, 5)
+        assert e.value.code == z.E_LIMIT and "LDS" in str(e.value)
+        ctx.release(tid)
+    finally:
+        ctx.close()
+
+
 def _ext_config(n, seed_inputs=6):
     g = z.default_generator_config()
     g.min_instructions = g.max_instructions = n

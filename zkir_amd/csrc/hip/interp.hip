@@ -649,6 +649,10 @@ static size_t interp_lds_bytes(int variant, uint32_t lslots, uint32_t strands, u
   if (variant == 3) return kTable29 + rows * kSlot29 + (strands ? (size_t)xslots * kWave29 : 0);
   return rows * 2 * kBlock * sizeof(uint4) + (strands ? (size_t)xslots * 2048 : 0);
 }
+// what a launch would ask of a CU's 160 KiB of LDS (the host refuses launches beyond it with a message of its own)
+size_t interp_lds_need(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots) {
+  return interp_lds_bytes(variant, lslots, strands, xslots);
+}
 // bytes of one witness slot of one workgroup in device memory
 size_t interp_slot_bytes(int variant) { return variant == 3 ? kSlot29 : (size_t)2 * kBlock * sizeof(uint4); }
 

@@ -23,6 +23,7 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
                          uint32_t* work_counter, uint32_t grid, uint32_t strands, uint32_t xslots, hipStream_t stream);
 hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots, int* blocks);
+size_t interp_lds_need(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots);
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream);
 hipError_t launch_consts_to_mont29(const uint32_t* canonical_dev, uint32_t* dst_dev, uint32_t n, hipStream_t stream);
 size_t interp_slot_bytes(int variant);
@@ -291,6 +292,11 @@ int32_t plan_group(zkir_ctx* ctx, const Group& G, int kind, uint64_t N, size_t p
     if (P->variant != 2 && P->variant != 3)
       return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 466 033 device slots per strand");
   }
+  const size_t lds = zkir::interp_lds_need(P->variant, G.max_lslots, P->strands, G.max_xslots);
+  if (lds > 160 * 1024)
+    return fail(ctx, ZKIR_E_LIMIT, "the tapes of this launch need " + std::to_string(lds) + " bytes of LDS per workgroup (" +
+                                       std::to_string(G.max_lslots) + " window rows, " + std::to_string(G.max_xslots) +
+                                       " exchange slots); a CU has 163840");
   P->grid = pick_grid(ctx, work, P->variant, G.max_lslots, P->strands, G.max_xslots);
   if (pool_rows_cap && G.max_gslots) {
     const uint64_t rows = (uint64_t)G.max_gslots * row_sets_of_kind(kind);
