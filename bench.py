@@ -43,7 +43,7 @@ def workload_tape(z, signal_window=0, linear_terms=1):
     g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = 16, 1, 1, 1
     g.no_loops, g.safe_array_index = 1, 1
     o = z.default_lower_options()
-    for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots", "strands", "max_xslots"):  # experiment knobs
+    for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots", "strands", "max_xslots", "reorder", "window_cache", "order_ops"):  # experiment knobs
         if os.environ.get("ZKIR_BENCH_" + k.upper()):
             setattr(o, k, int(os.environ["ZKIR_BENCH_" + k.upper()]))
     return z.Lowerer(z.Generator(WORKLOAD_SEED, g).generate(), o).lower()
@@ -55,7 +55,7 @@ def gadget_tape(z, rounds=20834, strands=0):
     batches that leave the machine short of wavefronts."""
     o = z.default_lower_options()
     o.strands = strands
-    for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots", "strands", "max_xslots"):
+    for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots", "strands", "max_xslots", "reorder", "window_cache", "order_ops"):
         if os.environ.get("ZKIR_BENCH_" + k.upper()):
             setattr(o, k, int(os.environ["ZKIR_BENCH_" + k.upper()]))
     return z.Lowerer(z.poseidon_style_gadget(4, rounds, 7), o).lower()

@@ -301,6 +301,9 @@ typedef struct zkir_lower_options {
                               the values read soonest (a value read again later
                               is also copied to a device slot); 0: a value lives
                               in the window or in device memory for all its life */
+  uint32_t order_ops;      /* 1: the ops of one statement run in the order that keeps
+                              the fewest temporaries alive (`A*B + C`: C first, so the
+                              product is forwarded into the sum); 0: as written  */
 } zkir_lower_options;
 
 int32_t zkir_lower_options_default(zkir_lower_options* o);

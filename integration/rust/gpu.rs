@@ -30,7 +30,7 @@ pub struct TapeHdr {
 pub struct LowerOptions {
     pub fold_constants: u32, pub n_lslots: u32, pub reuse_slots: u32, pub max_ops: u32, pub bnot_variant: u32,
     pub use_acc: u32, pub max_iterations: u32, pub window_lifetime: u32, pub strands: u32, pub max_xslots: u32,
-    pub reorder: u32, pub window_cache: u32,
+    pub reorder: u32, pub window_cache: u32, pub order_ops: u32,
 }
 
 #[link(name = "zkir_hip")]

@@ -40,6 +40,7 @@ for it in range(N):
     o.max_xslots = rnd.choice([0, 0, 6, 16])
     o.reorder = rnd.choice([0, 1, 1])
     o.window_cache = rnd.choice([0, 1, 1])
+    o.order_ops = rnd.choice([0, 1, 1])
     seed = rnd.randrange(1, 1 << 62)
     try:
         tape = z.Lowerer(z.Generator(seed, g).generate(), o).lower()

@@ -43,7 +43,7 @@ for it in range(N):
     seed = rnd.randrange(1, 1 << 62)
     c = z.Generator(seed, g).generate()
     base = z.default_lower_options()
-    base.reorder = base.window_cache = 0
+    base.reorder = base.window_cache = base.order_ops = 0
     base.max_iterations = 300
     base.fold_constants = rnd.choice([0, 1])
     base.bnot_variant = rnd.choice([0, 1])
@@ -68,6 +68,7 @@ for it in range(N):
         o.strands = rnd.choice([0, 0, 0, 4, 8])
         o.reorder = rnd.choice([0, 1, 1])
         o.window_cache = rnd.choice([0, 1, 1])
+        o.order_ops = rnd.choice([0, 1, 1])
         t = z.Lowerer(c, o).lower()
         z.Tape.from_parts(t.hdr, t.blob())
         reordered += any(op[0] >> 8 for op in t.ops()) and not t.hdr.flags

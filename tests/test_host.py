@@ -45,7 +45,7 @@ def test_abi_exports_every_declared_symbol():
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(api.TapeHdr) == 88
     assert ctypes.sizeof(api.GeneratorConfig) == 20 * 4
-    assert ctypes.sizeof(api.LowerOptions) == 12 * 4
+    assert ctypes.sizeof(api.LowerOptions) == 13 * 4
 
 
 def test_default_config_is_the_reference_literals():
@@ -355,7 +355,7 @@ def test_slot_allocation_options_do_not_change_results():
 
 
 def test_statement_order_and_window_policy_do_not_change_results():
-    """A plain tape with its statements reordered and its window run as a cache gives, vector for vector, the outputs,
+    """A plain tape with its statements reordered, the ops of each statement reordered and its window run as a cache gives, vector for vector, the outputs,
     the unsatisfied pairs and the first unsatisfied pair of the tape in program order (C checker, Python interpreter);
     a broken constraint keeps its number; the reordered tape moves fewer values through device slots."""
     import struct
@@ -365,16 +365,17 @@ def test_statement_order_and_window_policy_do_not_change_results():
     sys.path.insert(0, sys_path_tools)
     from slot_traffic import slot_traffic
     rnd = random.Random(4)
-    for seed, n_instr in ((5, 300), (9, 800), (11, 60)):
-        cfg = dict(EXT, arithmetic_only=1, quadratic_aware=1, no_loops=1, min_instructions=n_instr, max_instructions=n_instr)
+    for seed, n_instr, terms in ((5, 300, 1), (9, 800, 1), (11, 60, 1), (13, 400, 2)):
+        cfg = dict(EXT, arithmetic_only=1, quadratic_aware=1, no_loops=1, min_instructions=n_instr, max_instructions=n_instr,
+                   max_linear_terms=terms)
         c = z.Generator(seed, ext_config(**cfg)).generate()
         tapes = {}
-        for reorder, cache in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        for reorder, cache, within in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (0, 1, 1), (1, 1, 1)):
             o = z.default_lower_options()
-            o.reorder, o.window_cache = reorder, cache
-            tapes[reorder, cache] = z.Lowerer(c, o).lower()
-        ref = tapes[0, 0]
-        assert not any(op[0] >> 8 for op in ref.ops()) and all(op[0] >> 8 for op in tapes[1, 1].ops() if op[0] & 0xFF == F.OP_CHECK)
+            o.reorder, o.window_cache, o.order_ops = reorder, cache, within
+            tapes[reorder, cache, within] = z.Lowerer(c, o).lower()
+        ref = tapes[0, 0, 0]
+        assert not any(op[0] >> 8 for op in ref.ops()) and all(op[0] >> 8 for op in tapes[1, 1, 1].ops() if op[0] & 0xFF == F.OP_CHECK)
         vecs = [[rnd.randrange(F.P) for _ in range(ref.hdr.n_inputs)] for _ in range(9)]
         inp = z.pack_inputs(vecs, ref.hdr.n_inputs)
 
@@ -400,11 +401,15 @@ def test_statement_order_and_window_policy_do_not_change_results():
             assert F.eval_tape_one(t.ops(), t.consts(), vecs[0]) == F.eval_tape_one(ref.ops(), ref.consts(), vecs[0])
             z.Tape.from_parts(t.hdr, t.blob())  # validation accepts numbered CHECK ops in a plain tape
         if n_instr >= 300:
-            r0, w0, _ = slot_traffic(tapes[0, 0].ops())
-            r1, w1, _ = slot_traffic(tapes[1, 1].ops())
+            r0, w0, _ = slot_traffic(tapes[0, 0, 0].ops())
+            r1, w1, _ = slot_traffic(tapes[1, 1, 0].ops())
             assert r1 + w1 < r0 + w0, (r0, w0, r1, w1)
+        if terms == 2:  # `(a+b)*(c+d) + (e+f)`: with the addend first the product is never stored
+            r0, w0, _ = slot_traffic(tapes[0, 1, 0].ops())
+            r1, w1, _ = slot_traffic(tapes[0, 1, 1].ops())
+            assert r1 + w1 < 0.9 * (r0 + w0), (r0, w0, r1, w1)
     # numbers on some CHECK ops only: refused
-    t = tapes[1, 1]
+    t = tapes[1, 1, 1]
     ops = [list(op) for op in t.ops()]
     k = next(i for i, op in enumerate(ops) if op[0] & 0xFF == F.OP_CHECK)
     ops[k][0] &= 0xFF

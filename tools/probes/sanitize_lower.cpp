@@ -38,7 +38,7 @@ static int all_options(zkir_circuit* c) {
         for (uint32_t rows : {0u, 2u, 16u}) {
           zkir_lower_options o;
           zkir_lower_options_default(&o);
-          o.strands = strands; o.reorder = reorder; o.window_cache = cache; o.n_lslots = rows; o.max_iterations = 300;
+          o.strands = strands; o.reorder = reorder; o.window_cache = cache; o.order_ops = (rows >> 1) & 1u; o.n_lslots = rows; o.max_iterations = 300;
           if (lower_and_validate(c, o)) return 1;
         }
   return 0;

@@ -50,7 +50,7 @@ class GeneratorConfig(ctypes.Structure):
 
 class LowerOptions(ctypes.Structure):
     _fields_ = [(n, c_uint32) for n in ("fold_constants", "n_lslots", "reuse_slots", "max_ops", "bnot_variant",
-                                        "use_acc", "max_iterations", "window_lifetime", "strands", "max_xslots", "reorder", "window_cache")]
+                                        "use_acc", "max_iterations", "window_lifetime", "strands", "max_xslots", "reorder", "window_cache", "order_ops")]
 
 
 def _load():

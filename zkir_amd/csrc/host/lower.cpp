@@ -28,6 +28,7 @@ LowerOptions default_lower_options() {
   o.use_acc = 1;
   o.reorder = 1;
   o.window_cache = 1;
+  o.order_ops = 1;
   return o;
 }
 
@@ -1090,6 +1091,186 @@ std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std
   return out;
 }
 
+// ---- the order of the ops within one statement ----
+// Pass 1 emits the ops of a statement in the order the expression is written: for `out <== A*B + C` that is A, B,
+// the product, C, the sum.  The product then has to be kept somewhere while C is computed, next to A and B (the
+// CHECK reads them again) and C (the CHECK's right-hand side subtracts it): four temporaries.  With C first the
+// product goes from the multiplier straight into the sum (the accumulator forwards a value to the op after its
+// definition) and three temporaries remain.  Every temporary beyond the rows of the LDS window costs a store to and
+// a load from device memory per vector.  For each statement a few orders are tried (as written; operands of an op
+// in the order shallower chain first, deeper first, left first, right first) and the one with the fewest values
+// alive at once that are not forwarded is kept, then the fewest such values; ties keep the order as written.
+// Ops that define nothing (OUTPUT, CHECK) keep their relative order, so the k-th CHECK stays the k-th constraint.
+void order_within_statements(std::vector<SOp>& ops, const std::vector<uint32_t>& stmt_begin, int32_t nv) {
+  const size_t n = ops.size();
+  std::vector<uint32_t> begin;
+  for (uint32_t b : stmt_begin)
+    if (b < n && (begin.empty() || b > begin.back())) begin.push_back(b);
+  if (begin.empty() || begin[0] != 0) begin.insert(begin.begin(), 0u);
+  begin.push_back((uint32_t)n);
+  auto defines = [](const SOp& o) { return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP; };
+  auto sources = [](const SOp& o, Ref out[3]) {
+    out[0] = out[1] = out[2] = kNoRef;
+    if (o.code == ZKIR_OP_INPUT || o.code == ZKIR_OP_NOP) return;
+    out[0] = o.a;
+    out[1] = o.b;
+    if (o.code == ZKIR_OP_CHECK) out[2] = o.dst;
+  };
+  std::vector<uint32_t> total_uses(nv, 0);
+  for (const SOp& o : ops) {
+    Ref src[3];
+    sources(o, src);
+    for (Ref r : src)
+      if (r >= 0) total_uses[r]++;
+  }
+  constexpr size_t kMaxBlock = 48;  // longer statements (deep expressions) stay as written
+  std::vector<int32_t> local_of(nv, -1);  // value -> index within the block of the op that defines it
+  std::vector<SOp> blk, best_ops;
+  for (size_t bi = 0; bi + 1 < begin.size(); bi++) {
+    const uint32_t i0 = begin[bi], m = begin[bi + 1] - i0;
+    if (m < 4 || m > kMaxBlock) continue;
+    blk.assign(ops.begin() + i0, ops.begin() + i0 + m);
+    int32_t prod[kMaxBlock][3];   // producers within the block of each op's sources
+    uint8_t depth[kMaxBlock];
+    uint32_t uses_in[kMaxBlock];
+    bool is_root[kMaxBlock];
+    for (uint32_t j = 0; j < m; j++)
+      if (defines(blk[j]) && blk[j].dst >= 0) local_of[blk[j].dst] = (int32_t)j;
+    for (uint32_t j = 0; j < m; j++) {
+      uses_in[j] = 0;
+      is_root[j] = true;
+    }
+    bool forward_only = true;
+    for (uint32_t j = 0; j < m; j++) {
+      Ref src[3];
+      sources(blk[j], src);
+      depth[j] = 0;
+      for (int s = 0; s < 3; s++) {
+        const int32_t p = src[s] >= 0 ? local_of[src[s]] : -1;
+        prod[j][s] = p;
+        if (p < 0) continue;
+        if ((uint32_t)p >= j) forward_only = false;  // (cannot happen: a value is defined before it is read)
+        else {
+          uses_in[p]++;
+          is_root[p] = false;
+          depth[j] = std::max<uint8_t>(depth[j], (uint8_t)(depth[p] + 1));
+        }
+      }
+    }
+    auto cost_of = [&](const uint32_t* order) -> uint32_t {
+      // position of every op, then per defined value: is every read of it the accumulator's (no op that defines
+      // something between its definition and the read)?  The others are stored from their definition to their last read.
+      uint32_t pos[kMaxBlock], n_def_before[kMaxBlock + 1];
+      n_def_before[0] = 0;
+      for (uint32_t q = 0; q < m; q++) {
+        pos[order[q]] = q;
+        n_def_before[q + 1] = n_def_before[q] + (defines(blk[order[q]]) ? 1u : 0u);
+      }
+      uint32_t last_use[kMaxBlock];
+      bool stored[kMaxBlock];
+      for (uint32_t j = 0; j < m; j++) {
+        last_use[j] = pos[j];
+        const bool escapes = defines(blk[j]) && blk[j].dst >= 0 && total_uses[blk[j].dst] > uses_in[j];
+        stored[j] = escapes;
+        if (escapes) last_use[j] = m;
+      }
+      for (uint32_t j = 0; j < m; j++)
+        for (int s = 0; s < 3; s++) {
+          const int32_t p = prod[j][s];
+          if (p < 0) continue;
+          last_use[p] = std::max(last_use[p], pos[j]);
+          if (n_def_before[pos[j]] - n_def_before[pos[p] + 1] != 0) stored[p] = true;
+        }
+      int32_t delta[kMaxBlock + 2] = {0};
+      uint32_t n_stored = 0;
+      for (uint32_t j = 0; j < m; j++)
+        if (stored[j] && defines(blk[j])) {
+          n_stored++;
+          delta[pos[j]]++;
+          delta[last_use[j] + 1]--;
+        }
+      int32_t live = 0, peak = 0;
+      for (uint32_t q = 0; q <= m; q++) {
+        live += delta[q];
+        peak = std::max(peak, live);
+      }
+      return (uint32_t)peak * 256u + n_stored;
+    };
+    // only an op that reads two values made in this statement leaves a choice
+    bool any_choice = false;
+    for (uint32_t j = 0; j < m && !any_choice; j++) {
+      int np = 0;
+      for (int s = 0; s < 3; s++) np += prod[j][s] >= 0 && (s == 0 || prod[j][s] != prod[j][0]);
+      any_choice = np >= 2;
+    }
+    if (!any_choice) forward_only = false;
+    uint32_t order[kMaxBlock], best_order[kMaxBlock];
+    for (uint32_t j = 0; j < m; j++) best_order[j] = j;
+    uint32_t best = forward_only ? cost_of(best_order) : 0;
+    for (int rule = 0; forward_only && rule < 4; rule++) {
+      bool emitted[kMaxBlock] = {false};
+      uint32_t n_out = 0;
+      // depth-first from the ops nothing in the statement reads, in the order written; explicit stack of (op, next source)
+      uint32_t stack_op[kMaxBlock], stack_at[kMaxBlock];
+      for (uint32_t root = 0; root < m; root++) {
+        if (!is_root[root] || emitted[root]) continue;
+        uint32_t sp = 0;
+        stack_op[sp] = root;
+        stack_at[sp++] = 0;
+        while (sp) {
+          const uint32_t j = stack_op[sp - 1];
+          // the producers of j in the order of this rule
+          int32_t ps[3];
+          int np = 0;
+          for (int s = 0; s < 3; s++)
+            if (prod[j][s] >= 0) ps[np++] = prod[j][s];
+          if (rule == 3) std::reverse(ps, ps + np);
+          if (rule < 2)  // insertion sort of at most three, stable
+            for (int x = 1; x < np; x++)
+              for (int y = x; y > 0 && (rule == 0 ? depth[ps[y]] < depth[ps[y - 1]] : depth[ps[y]] > depth[ps[y - 1]]); y--)
+                std::swap(ps[y], ps[y - 1]);
+          bool pushed = false;
+          while ((int)stack_at[sp - 1] < np) {
+            const int32_t p = ps[stack_at[sp - 1]++];
+            if (!emitted[p]) {
+              emitted[p] = true;  // (marks "on the stack or out": an op is pushed once)
+              stack_op[sp] = (uint32_t)p;
+              stack_at[sp++] = 0;
+              pushed = true;
+              break;
+            }
+          }
+          if (pushed) continue;
+          emitted[j] = true;
+          order[n_out++] = j;
+          sp--;
+        }
+      }
+      if (n_out != m) continue;
+      const uint32_t c = cost_of(order);
+      if (c < best) {
+        best = c;
+        std::copy(order, order + m, best_order);
+      }
+    }
+    for (uint32_t j = 0; j < m; j++)
+      if (defines(blk[j]) && blk[j].dst >= 0) local_of[blk[j].dst] = -1;
+    bool changed = false;
+    for (uint32_t j = 0; j < m; j++) changed = changed || best_order[j] != j;
+    if (!changed) continue;
+    // ops that define nothing keep the order they were written in (constraint numbers follow the CHECKs)
+    uint32_t sinks[kMaxBlock], n_sinks = 0;
+    for (uint32_t j = 0; j < m; j++)
+      if (!defines(blk[j])) sinks[n_sinks++] = j;
+    uint32_t at = 0;
+    bool sinks_in_order = true;
+    for (uint32_t q = 0; q < m; q++)
+      if (!defines(blk[best_order[q]])) sinks_in_order = sinks_in_order && best_order[q] == sinks[at++];
+    if (!sinks_in_order) continue;
+    for (uint32_t q = 0; q < m; q++) ops[i0 + q] = blk[best_order[q]];
+  }
+}
+
 // ---- strands: which op runs in which of the four op streams, and between which barriers ----
 // The strands advance in epochs (the stretches between barriers): an op may use a value of
 // its own strand at once, a value of another strand only in a later epoch.  The schedule is
@@ -1352,6 +1533,7 @@ Tape Lowerer::lower() {
     throw LowerError(ZKIR_LOWER_BAD_AST, "strands must be 0, 4 or 8");
   Pass1 p1(circuit, opts_);
   p1.run();
+  if (opts_.order_ops) order_within_statements(p1.ops, p1.stmt_begin, p1.n_values);
   const std::vector<SOp>& ops = p1.ops;
   const size_t n = ops.size();
   const int32_t nv = p1.n_values;
