@@ -8,6 +8,7 @@
 #include "lower.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -1097,9 +1098,11 @@ std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std
 // CHECK reads them again) and C (the CHECK's right-hand side subtracts it): four temporaries.  With C first the
 // product goes from the multiplier straight into the sum (the accumulator forwards a value to the op after its
 // definition) and three temporaries remain.  Every temporary beyond the rows of the LDS window costs a store to and
-// a load from device memory per vector.  For each statement a few orders are tried (as written; operands of an op
-// in the order shallower chain first, deeper first, left first, right first) and the one with the fewest values
-// alive at once that are not forwarded is kept, then the fewest such values; ties keep the order as written.
+// a load from device memory per vector.  For each statement the order "operands of an op: the shallower chain first"
+// (depth-first from the ops nothing in the statement reads) is compared with the order as written: the one with the
+// fewest values alive at once that are not forwarded is kept, then the fewest such values; ties keep the order as
+// written.  (Deeper-first, left-first and right-first orders were tried too: on generated circuits they win in one
+// statement in a hundred, for a third of the host time of this pass.)
 // Ops that define nothing (OUTPUT, CHECK) keep their relative order, so the k-th CHECK stays the k-th constraint.
 void order_within_statements(std::vector<SOp>& ops, const std::vector<uint32_t>& stmt_begin, int32_t nv) {
   const size_t n = ops.size();
@@ -1124,12 +1127,13 @@ void order_within_statements(std::vector<SOp>& ops, const std::vector<uint32_t>&
       if (r >= 0) total_uses[r]++;
   }
   constexpr size_t kMaxBlock = 48;  // longer statements (deep expressions) stay as written
+  static thread_local std::unordered_map<uint64_t, std::array<uint8_t, kMaxBlock + 1>> shape_cache;
   std::vector<int32_t> local_of(nv, -1);  // value -> index within the block of the op that defines it
-  std::vector<SOp> blk, best_ops;
+  SOp moved[kMaxBlock];
   for (size_t bi = 0; bi + 1 < begin.size(); bi++) {
     const uint32_t i0 = begin[bi], m = begin[bi + 1] - i0;
     if (m < 4 || m > kMaxBlock) continue;
-    blk.assign(ops.begin() + i0, ops.begin() + i0 + m);
+    const SOp* blk = ops.data() + i0;
     int32_t prod[kMaxBlock][3];   // producers within the block of each op's sources
     uint8_t depth[kMaxBlock];
     uint32_t uses_in[kMaxBlock];
@@ -1206,8 +1210,41 @@ void order_within_statements(std::vector<SOp>& ops, const std::vector<uint32_t>&
     if (!any_choice) forward_only = false;
     uint32_t order[kMaxBlock], best_order[kMaxBlock];
     for (uint32_t j = 0; j < m; j++) best_order[j] = j;
-    uint32_t best = forward_only ? cost_of(best_order) : 0;
-    for (int rule = 0; forward_only && rule < 4; rule++) {
+    // Generated circuits repeat a handful of statement shapes thousands of times: the answer is remembered per shape
+    // (which ops define a value, which op of the statement makes each source, which values are read elsewhere).  A
+    // remembered order is checked against this statement before it is used, so two shapes with one key cost a
+    // good order, never a wrong tape.
+    uint64_t key = 1469598103934665603ull ^ m;
+    if (forward_only) {
+      for (uint32_t j = 0; j < m; j++) {
+        const bool def = defines(blk[j]);
+        const uint32_t word = (uint32_t)(prod[j][0] + 1) | (uint32_t)(prod[j][1] + 1) << 6 | (uint32_t)(prod[j][2] + 1) << 12 |
+                              (def ? 1u << 18 : 0u) | (def && blk[j].dst >= 0 && total_uses[blk[j].dst] > uses_in[j] ? 1u << 19 : 0u);
+        key = (key ^ word) * 1099511628211ull;
+      }
+      const auto hit = shape_cache.find(key);
+      if (hit != shape_cache.end() && hit->second[0] == m) {
+        bool ok = true;
+        uint32_t pos[kMaxBlock];
+        uint64_t seen = 0;
+        for (uint32_t q = 0; q < m && ok; q++) {
+          const uint32_t j = hit->second[q + 1];
+          ok = j < m && !(seen >> j & 1);
+          if (ok) {
+            seen |= 1ull << j;
+            pos[j] = q;
+          }
+        }
+        for (uint32_t j = 0; j < m && ok; j++)
+          for (int s = 0; s < 3; s++) ok = ok && (prod[j][s] < 0 || pos[prod[j][s]] < pos[j]);
+        if (ok) {
+          for (uint32_t q = 0; q < m; q++) best_order[q] = hit->second[q + 1];
+          forward_only = false;  // nothing left to search
+        }
+      }
+    }
+    const bool searched = forward_only;
+    if (forward_only) {
       bool emitted[kMaxBlock] = {false};
       uint32_t n_out = 0;
       // depth-first from the ops nothing in the statement reads, in the order written; explicit stack of (op, next source)
@@ -1219,16 +1256,13 @@ void order_within_statements(std::vector<SOp>& ops, const std::vector<uint32_t>&
         stack_at[sp++] = 0;
         while (sp) {
           const uint32_t j = stack_op[sp - 1];
-          // the producers of j in the order of this rule
+          // the producers of j, the shallowest first (insertion sort of at most three, stable)
           int32_t ps[3];
           int np = 0;
           for (int s = 0; s < 3; s++)
             if (prod[j][s] >= 0) ps[np++] = prod[j][s];
-          if (rule == 3) std::reverse(ps, ps + np);
-          if (rule < 2)  // insertion sort of at most three, stable
-            for (int x = 1; x < np; x++)
-              for (int y = x; y > 0 && (rule == 0 ? depth[ps[y]] < depth[ps[y - 1]] : depth[ps[y]] > depth[ps[y - 1]]); y--)
-                std::swap(ps[y], ps[y - 1]);
+          for (int x = 1; x < np; x++)
+            for (int y = x; y > 0 && depth[ps[y]] < depth[ps[y - 1]]; y--) std::swap(ps[y], ps[y - 1]);
           bool pushed = false;
           while ((int)stack_at[sp - 1] < np) {
             const int32_t p = ps[stack_at[sp - 1]++];
@@ -1246,12 +1280,15 @@ void order_within_statements(std::vector<SOp>& ops, const std::vector<uint32_t>&
           sp--;
         }
       }
-      if (n_out != m) continue;
-      const uint32_t c = cost_of(order);
-      if (c < best) {
-        best = c;
-        std::copy(order, order + m, best_order);
-      }
+      bool same = n_out == m;
+      for (uint32_t q = 0; q < m && same; q++) same = order[q] == q;
+      if (n_out == m && !same && cost_of(order) < cost_of(best_order)) std::copy(order, order + m, best_order);
+    }
+    if (searched) {
+      if (shape_cache.size() > 4096) shape_cache.clear();
+      std::array<uint8_t, kMaxBlock + 1>& entry = shape_cache[key];
+      entry[0] = (uint8_t)m;
+      for (uint32_t q = 0; q < m; q++) entry[q + 1] = (uint8_t)best_order[q];
     }
     for (uint32_t j = 0; j < m; j++)
       if (defines(blk[j]) && blk[j].dst >= 0) local_of[blk[j].dst] = -1;
@@ -1267,7 +1304,8 @@ void order_within_statements(std::vector<SOp>& ops, const std::vector<uint32_t>&
     for (uint32_t q = 0; q < m; q++)
       if (!defines(blk[best_order[q]])) sinks_in_order = sinks_in_order && best_order[q] == sinks[at++];
     if (!sinks_in_order) continue;
-    for (uint32_t q = 0; q < m; q++) ops[i0 + q] = blk[best_order[q]];
+    for (uint32_t q = 0; q < m; q++) moved[q] = blk[best_order[q]];
+    std::copy(moved, moved + m, ops.begin() + i0);
   }
 }
 
