@@ -95,6 +95,7 @@ class Lane:
         self.pending = {}  # register -> "vm" | "lgkm": a load not yet waited for
         self.stores_waited = True  # no store (LDS or device memory) issued since the last full wait
         self.steps = 0
+        self.prio, self.prio_log, self.clock = 0, [], 0  # s_setprio history; the value s_memrealtime returns
         self.counts = {}
         self.wrap_ok = set()  # destination registers whose v_add_u32 may wrap (signed limb arithmetic), by name
 
@@ -330,6 +331,18 @@ class Lane:
                 nxt = labels[a[0]]
         elif op == "s_nop":
             pass
+        elif op == "s_setprio":
+            v = self.imm(a[0])
+            if v > 3:
+                raise ModelError("s_setprio %d: priorities are 0..3" % v)
+            self.prio = v
+            self.prio_log.append(v)
+        elif op == "s_memrealtime":
+            # the constant-rate clock: the test sets self.clock; the value arrives like a scalar load
+            lo, hi = self.srange(a[0], 2)
+            self.swrite(lo, self.clock & M32)
+            self.swrite(hi, self.clock >> 32)
+            self.pending[lo] = self.pending[hi] = "lgkm"
         elif op == "s_barrier":
             # what another wavefront is to see must have left this one: no memory operation in flight
             if self.pending:

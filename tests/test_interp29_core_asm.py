@@ -100,7 +100,7 @@ def run_lane(ops, consts, inputs, n_outputs, n_lslots, n_gslots, vec, wave=0, la
         "%[in_base]": IN_BASE, "%[out_base]": OUT_BASE if want_outputs else 0,
         "%[n4]": 4 * n_vec, "%[live]": (0x8000000000000001 | bit) if live else (0x8000000000000001 & ~bit),
         "%[v_lo]": wave * WAVE + lane * 16, "%[v_lo4]": wave * WAVE + 2048 + lane * 4, "%[v_vec4]": 4 * v,
-        "%[xbase]": xbase, "%[v_x]": lane * 16, "%[v_x4]": 2048 + lane * 4,
+        "%[xbase]": xbase, "%[v_x]": lane * 16, "%[v_x4]": 2048 + lane * 4, "%[rot]": 0xFFFFFFFF, "%[rot_shift]": 12,
     }
     ln = make_lane(mem, xbase + n_xslots * WAVE, lane, operands)
     ln.lds = table_lds()
@@ -347,9 +347,11 @@ def test_operand_registers_are_reused_and_invalidated():
 
 
 # ---- strand tapes: four wavefronts, one lane of each, sharing LDS and the output buffer -------------
-def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, n_xslots, vec, lane=0):
+def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, n_xslots, vec, lane=0, rot=0xFFFFFFFF,
+                clock_step=0, prio_logs=None):
     """One lane of each wavefront (four or eight: len(strand_ops)) with the operands the kernel around the stream gives
-    them: eight wavefronts keep two sets of slot rows, wavefronts 4..7 use the second."""
+    them: eight wavefronts keep two sets of slot rows, wavefronts 4..7 use the second.  rot: the workgroup's phase in
+    the priority turns (0xFFFFFFFF: none); the model's clock advances by clock_step per barrier."""
     n_vec = len(inputs)
     n_str = len(strand_ops)
     sets = 2 if n_str == 8 else 1
@@ -366,7 +368,7 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
             "%[lds_base]": lds_rows + (w >> 2) * n_lslots * SLOT, "%[lds_tab]": TAB_BASE, "%[evict_below]": 0,
             "%[in_base]": IN_BASE, "%[out_base]": OUT_BASE, "%[n4]": 4 * n_vec, "%[live]": 0x8000000000000001 | (1 << lane),
             "%[v_lo]": (w & 3) * WAVE + lane * 16, "%[v_lo4]": (w & 3) * WAVE + 2048 + lane * 4, "%[v_vec4]": 4 * vec,
-            "%[xbase]": xbase, "%[v_x]": lane * 16, "%[v_x4]": 2048 + lane * 4,
+            "%[xbase]": xbase, "%[v_x]": lane * 16, "%[v_x4]": 2048 + lane * 4, "%[rot]": rot, "%[rot_shift]": 12,
         }
         ln = make_lane(mem, xbase + n_xslots * WAVE, lane, operands)
         ln.lds = shared_lds
@@ -377,10 +379,13 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
     while any(pc is not None for pc in pcs):
         for w in range(n_str):
             if pcs[w] is not None:
+                lanes[w].clock = (1 << 40) + clock_step * arrived[w]
                 pcs[w] = lanes[w].run(PROG, LABELS, pc=pcs[w], stop_at_barrier=True)
                 arrived[w] += pcs[w] is not None
         assert len({a for a, pc in zip(arrived, pcs) if pc is not None}) <= 1, "wavefronts wait at different barriers"
     assert len(set(arrived)) == 1
+    if prio_logs is not None:
+        prio_logs.extend(ln.prio_log for ln in lanes)
     outs = read_outputs(out_region, n_outputs, n_vec, vec)
     return outs, sum(ln.operand_written["%[unsat]"] for ln in lanes), min(ln.operand_written["%[first]"] for ln in lanes)
 
@@ -415,3 +420,33 @@ def test_strand_tapes_on_the_model(n_strands):
         outs, unsat, first = run_strands(bad, so, consts, inputs, t.hdr.n_outputs, t.hdr.n_lslots, t.hdr.n_gslots,
                                          t.hdr.n_xslots, 1, 5)
         assert want_unsat == [5] and unsat == 1 and first == 5
+
+
+def test_priority_turns_of_a_strand_tape():
+    """With turns on, every barrier sets the wavefront's priority to ((clock >> shift) + phase) & 3: the workgroups of
+    a CU (phases 0..3) hold four different priorities at any time, each priority for a quarter of the time; results do
+    not change; without turns the stream never touches the priority."""
+    import zkir_amd as z
+    o = z.default_lower_options()
+    o.strands = 4
+    t = z.Lowerer(z.poseidon_style_gadget(4, 6, 2), o).lower()
+    ops, consts, so = t.ops(), t.consts(), list(t.hdr.strand_ops)[:4]
+    rnd = random.Random(5)
+    inputs = [[rnd.randrange(F.P) for _ in range(4)] for _ in range(2)]
+    want, _, _ = F.eval_tape_one(ops, consts, inputs[1], strand_ops=so)
+    n_barriers = sum(1 for op in ops[:so[0]] if op[0] & 0xFF == F.OP_BARRIER)
+    assert n_barriers >= 4
+    per_phase = []
+    for phase in (0, 1, 2, 3, 0xFFFFFFFF):
+        logs = []
+        outs, unsat, _ = run_strands(ops, so, consts, inputs, t.hdr.n_outputs, t.hdr.n_lslots, t.hdr.n_gslots, t.hdr.n_xslots,
+                                     1, 9, rot=phase, clock_step=1 << 12, prio_logs=logs)
+        assert outs == [want[k] for k in range(t.hdr.n_outputs)] and unsat == 0
+        if phase == 0xFFFFFFFF:
+            assert all(log == [0] for log in logs)  # only the reset at the end of the stream
+        else:
+            # the clock advances one turn per barrier in this run: barrier k sets (k + phase) & 3; then the final reset
+            assert all(log == [(k + phase) & 3 for k in range(n_barriers)] + [0] for log in logs)
+            per_phase.append(logs[0][:n_barriers])
+    for k in range(n_barriers):
+        assert sorted(p[k] for p in per_phase) == [0, 1, 2, 3]

@@ -92,7 +92,9 @@ CST_LAST = "s%d" % (SB + 52)  # the ninth limb of a constant
 cst_word = lambda j: "s%d" % (SB + 44 + j)
 TAG_V = "s%d" % (SB + 41)  # device-slot operand word whose value sits in the victim row of LDS
 SQ = "s%d" % (SB + 53)    # Q_CONST
-S_LAST = SB + 53
+NOW = "s[%d:%d]" % (SB + 54, SB + 55)  # the constant-rate clock, read at a barrier (strand tapes with priority turns)
+NOW_LO = "s%d" % (SB + 54)
+S_LAST = SB + 55
 assert S_LAST <= 99  # s100 and above are reserved by the compiler on this target
 
 K_GSLOT, K_LSLOT, K_CONST, K_INPUT, K_ACC, K_NONE, K_XSLOT = 0, 1, 2, 3, 4, 5, 6
@@ -108,6 +110,9 @@ IN_EVICT = "%[evict_below]"  # 0x20000000 when the launch has a victim row, 0 wh
 IN_XBASE, IN_VX = "%[xbase]", "%[v_x]"  # strand tapes: LDS address of the exchange slots, lane * 16
 IN_VLO4, IN_VX4 = "%[v_lo4]", "%[v_x4]"  # plane 2 of a slot: wave * 2304 + 2048 + lane * 4; 2048 + lane * 4
 IN_TAB = "%[lds_tab]"  # LDS address of the table of q * p, 48 bytes per entry, q < 32
+IN_ROT = "%[rot]"      # which of the workgroups resident on its CU this one is (0..3): the phase of its priority
+                       # turns; -1: no turns
+IN_ROTSH = "%[rot_shift]"  # a turn lasts 1 << rot_shift ticks of the 100 MHz clock
 OUT_UNSAT, OUT_FIRST = "%[unsat]", "%[first]"
 
 
@@ -453,8 +458,40 @@ def build():
     a.e("s_cbranch_scc0 .Lz29_next")  # NOP and anything unknown
     # BARRIER: everything this wavefront stored is visible to the workgroup once its memory
     # operations have completed; then wait for the other strands
+    a.e("s_cmp_eq_u32 %s, -1" % IN_ROT)
+    a.e("s_cbranch_scc0 .Lz29_barrier_turn")
     a.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a.e("s_barrier")
+    a.e("s_branch .Lz29_next")
+    # The SIMD issues from its oldest wavefront first, so of the workgroups resident on a CU the first one placed
+    # runs ahead and the last one finishes alone, on SIMDs it cannot fill (measured on four workgroups of four
+    # strands with one work item each: 56, 69, 87 and 106 ms for the same work).  Priorities that turn with the
+    # clock, each resident workgroup in a different phase, give every workgroup the same share: they finish
+    # together.  (Turns counted in barriers instead of clock ticks drift apart between workgroups, which then hold
+    # equal priorities much of the time: a third of the gain.  Turns shorter than 40 us or longer than 1 ms lose too.)
+    a.label(".Lz29_barrier_turn")
+    a.e("s_memrealtime %s" % NOW)
+    a.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    a.e("s_barrier")
+    a.e("s_lshr_b32 %s, %s, %s" % (T0, NOW_LO, IN_ROTSH))
+    a.e("s_add_u32 %s, %s, %s" % (T0, T0, IN_ROT))
+    a.e("s_and_b32 %s, %s, 3" % (T0, T0))
+    a.e("s_cmp_lt_u32 %s, 2" % T0)
+    a.e("s_cbranch_scc1 .Lz29_prio01")
+    a.e("s_cmp_eq_u32 %s, 2" % T0)
+    a.e("s_cbranch_scc1 .Lz29_prio2")
+    a.e("s_setprio 3")
+    a.e("s_branch .Lz29_next")
+    a.label(".Lz29_prio2")
+    a.e("s_setprio 2")
+    a.e("s_branch .Lz29_next")
+    a.label(".Lz29_prio01")
+    a.e("s_cmp_eq_u32 %s, 0" % T0)
+    a.e("s_cbranch_scc1 .Lz29_prio0")
+    a.e("s_setprio 1")
+    a.e("s_branch .Lz29_next")
+    a.label(".Lz29_prio0")
+    a.e("s_setprio 0")
     a.e("s_branch .Lz29_next")
 
     def io_descriptor(base, index_reg):
@@ -574,6 +611,7 @@ def build():
     a.e("s_cbranch_scc1 .Lz29_top")
 
     a.label(".Lz29_end")
+    a.e("s_setprio 0")
     a.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a.e("s_mov_b64 %s, %s" % (OUT_UNSAT, UNSAT))
     a.e("v_mov_b32 %s, %s" % (OUT_FIRST, FIRST))

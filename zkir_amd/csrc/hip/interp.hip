@@ -439,7 +439,7 @@ zkir_interp_lean29_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, 
                           uint64_t n_vectors, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ outputs,
                           uint4* __restrict__ gslot_pool, uint32_t gslots_per_block,
                           uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats,
-                          uint32_t* __restrict__ work_counter, uint32_t victim_row, uint32_t strands, uint32_t lslots) {
+                          uint32_t* __restrict__ work_counter, uint32_t victim_row, uint32_t strands, uint32_t lslots, uint32_t turns) {
   __shared__ uint32_t next_item;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
   const uint32_t row_sets = strands == 8u ? 2u : 1u, set = wave >> 2;  // as in zkir_interp_lean_kernel
@@ -455,6 +455,11 @@ zkir_interp_lean29_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, 
   const uint32_t v_lo = (wave & 3u) * kWave29 + lane * 16u, v_lo4 = (wave & 3u) * kWave29 + 2048u + lane * 4u;
   const uint32_t v_x = lane * 16u, v_x4 = 2048u + lane * 4u;
   const uint32_t n4 = (uint32_t)n_vectors * 4u;
+  // priority turns of a strand tape (turns = CUs | log2 of the turn in clock ticks << 16; 0: none): workgroups are
+  // placed CU by CU in the order of their numbers, so the ones that share a CU are one CU count apart and the
+  // quotient tells them apart
+  const uint32_t rot = turns ? __builtin_amdgcn_readfirstlane(blockIdx.x / (turns & 0xffffu)) : 0xffffffffu;
+  const uint32_t rot_shift = turns >> 16;
   if (threadIdx.x < 32) {  // entry q: the limbs of q*p, 12 words (9 used)
     uint32_t* row = (uint32_t*)zkir_lds_slots + threadIdx.x * 12;
     uint64_t carry = 0;
@@ -496,7 +501,7 @@ zkir_interp_lean29_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, 
                  : [ops] "s"(ops), [n_ops] "s"(n_ops), [consts] "s"(consts), [n_consts] "s"(td.n_consts),
                    [gslots] "s"(gslots), [gslot_bytes] "s"(gslot_bytes), [lds_base] "s"(lds_base), [lds_tab] "s"(lds_tab),
                    [in_base] "s"(in_base), [out_base] "s"(out_base), [n4] "s"(n4), [live] "s"(live_mask),
-                   [evict_below] "s"(evict_below), [xbase] "s"(xbase), [v_lo] "v"(v_lo), [v_lo4] "v"(v_lo4),
+                   [evict_below] "s"(evict_below), [xbase] "s"(xbase), [rot] "s"(rot), [rot_shift] "s"(rot_shift), [v_lo] "v"(v_lo), [v_lo4] "v"(v_lo4),
                    [v_vec4] "v"(v_vec4), [v_x] "v"(v_x), [v_x4] "v"(v_x4)
                  : ZKIR_INTERP29_CORE_CLOBBERS);
 
@@ -659,7 +664,9 @@ size_t interp_slot_bytes(int variant) { return variant == 3 ? kSlot29 : (size_t)
 hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
-                         uint32_t* work_counter, uint32_t grid, uint32_t strands, uint32_t xslots, hipStream_t stream) {
+                         uint32_t* work_counter, uint32_t grid, uint32_t strands, uint32_t xslots, uint32_t n_cu,
+                         hipStream_t stream) {
+  if (n_cu == 0 || n_cu > 0xffffu) return hipErrorInvalidValue;
   const size_t lds_bytes = interp_lds_bytes(variant, lslots, strands, xslots);
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if ((variant == 2 || variant == 3) && n_vectors * 32 >= (1ull << 32)) return hipErrorInvalidValue;
@@ -673,10 +680,14 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
     if (e != hipSuccess) return e;
   }
   uint4* pool = (uint4*)gslot_pool;
-  // the last three are read by the generated-stream kernel only
+  // the last four are read by the generated-stream kernels only (turns by the 29-bit one)
   uint32_t victim_row = interp_victim_row(variant, lslots, strands) ? 1u : 0u;
+  // A strand launch with several workgroups per CU: the workgroups take turns at the SIMDs' issue priority (164 us
+  // each) instead of running in the order they were placed, the last one finishing alone.
+  static const uint32_t turn_shift = std::getenv("ZKIR_TURN_SHIFT") ? (uint32_t)std::atoi(std::getenv("ZKIR_TURN_SHIFT")) : 14u;  // measurement aid; 99: no turns
+  uint32_t turns = strands && grid > n_cu && turn_shift < 32 ? (n_cu | turn_shift << 16) : 0u;
   void* args[] = {&tapes_dev, &n_tapes, &passes_per_tape, &n_vectors, &inputs, &outputs, &pool, &gslots_per_block,
-                  &unsat_per_tape, &stats, &work_counter, &victim_row, &strands, &lslots};
+                  &unsat_per_tape, &stats, &work_counter, &victim_row, &strands, &lslots, &turns};
   return hipLaunchKernel(interp_entry(variant), dim3(grid), dim3(strands == 8 ? 2 * kBlock : kBlock), args, lds_bytes, stream);
 }
 

@@ -21,7 +21,8 @@ namespace zkir {
 hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
-                         uint32_t* work_counter, uint32_t grid, uint32_t strands, uint32_t xslots, hipStream_t stream);
+                         uint32_t* work_counter, uint32_t grid, uint32_t strands, uint32_t xslots, uint32_t n_cu,
+                         hipStream_t stream);
 hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots, int* blocks);
 size_t interp_lds_need(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots);
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream);
@@ -277,16 +278,18 @@ struct Plan {
 // pool_rows_cap: 0, or the slot rows (8 KiB each) the caller's fixed pool holds; the grid shrinks to fit
 int32_t plan_group(zkir_ctx* ctx, const Group& G, int kind, uint64_t N, size_t pool_rows_cap, Plan* P) {
   P->strands = strands_of_kind(kind);
-  // a pass is one workgroup's worth of vectors: 256, or 64 when its wavefronts are the strands
-  const uint32_t per_pass = kind ? 64u : (uint32_t)ZKIR_BLOCK_THREADS;
-  P->passes = (uint32_t)((N + per_pass - 1) / per_pass);
-  const uint64_t work = (uint64_t)G.count * P->passes;
-  if (work >= (1ull << 32) - (1u << 20)) return fail(ctx, ZKIR_E_LIMIT, "too many (tape, pass) work items for one launch");
   P->variant = pick_variant(G.full, N, G.max_gslots);
   if (kind && P->variant == 0) {  // ZKIR_INTERP=compiled: strand tapes still take a generated stream
     const char* want = std::getenv("ZKIR_INTERP");
     if (want && std::strcmp(want, "compiled") == 0 && (uint64_t)G.max_gslots * kSlotBytesMax < (1ull << 32)) P->variant = 3;
   }
+  // a pass is one workgroup's worth of vectors: 256, or 64 when its wavefronts are the strands.  (A wavefront of a
+  // plain tape taking 64-vector items on its own was tried, to shorten the end of a launch: no gain on the
+  // benchmark's launch, 7 % slower on the 29-bit stream, whose four wavefronts then stop reading neighbouring rows.)
+  const uint32_t per_pass = kind ? 64u : (uint32_t)ZKIR_BLOCK_THREADS;
+  P->passes = (uint32_t)((N + per_pass - 1) / per_pass);
+  const uint64_t work = (uint64_t)G.count * P->passes;
+  if (work >= (1ull << 32) - (1u << 20)) return fail(ctx, ZKIR_E_LIMIT, "too many (tape, pass) work items for one launch");
   if (kind) {  // only the generated stream runs strand tapes (upload refused any other operator)
     if (N * 32 >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 2^27 vectors per launch");
     if (P->variant != 2 && P->variant != 3)
@@ -339,7 +342,7 @@ int32_t launch_group(zkir_ctx* ctx, const Group& G, const Plan& P, const TapeDes
                      uint32_t* out_dev, void* pool, uint32_t* counter, uint64_t* unsat_dev, uint64_t* stats_dev,
                      hipStream_t stream) {
   hipError_t e = zkir::launch_interp(P.variant, descs_dev, G.count, P.passes, N, in_dev, out_dev, pool, G.max_gslots,
-                                     G.max_lslots, unsat_dev, stats_dev, counter, P.grid, P.strands, G.max_xslots, stream);
+                                     G.max_lslots, unsat_dev, stats_dev, counter, P.grid, P.strands, G.max_xslots, (uint32_t)ctx->n_cu, stream);
   if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
   return ZKIR_OK;
 }
