@@ -88,6 +88,12 @@ def test_generator_matches_restatement_over_seeds():
     for seed in range(1, 8):
         assert z.Generator(seed, ext_config(**cfg)).generate().text() == \
             R.print_text(R.Generator(R.Rng(seed), **cfg).generate())
+    # hundreds of written arrays: gen_array_index's one draw per array goes through the generator's jump tables
+    cfg = dict(cfg, min_instructions=1500, max_instructions=1500)
+    for seed in (3, 4):
+        text = z.Generator(seed, ext_config(**cfg)).generate().text()
+        assert text == R.print_text(R.Generator(R.Rng(seed), **cfg).generate())
+        assert text.count("(array ") > 100
     cfg = dict(min_instructions=40, max_instructions=80, max_expr_depth=3, inputs_readable=1, safe_array_index=1)
     for seed in range(1, 40):
         assert z.Generator(seed, ext_config(**cfg)).generate().text() == \

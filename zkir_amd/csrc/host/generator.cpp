@@ -141,8 +141,9 @@ Circuit Generator::generate() {
   const size_t n = rng_.rand(cfg_.min_instructions, cfg_.max_instructions);
   requested_ = n;
   instructions.reserve(n + n / 2 + cfg_.forced_inputs);
-  scope_stack_.flat.reserve(n / 2 + cfg_.forced_inputs + 16);
-  scope_stack_.all_vars.reserve(n / 2 + cfg_.forced_inputs + 16);
+  // at most one declaration per statement, plus the output a quadratic-aware constraint declares for itself
+  scope_stack_.flat.reserve(n + cfg_.forced_inputs + 16);
+  scope_stack_.all_vars.reserve(n + cfg_.forced_inputs + 16);
 
   // extension: scalar input signals declared before anything else
   for (uint32_t k = 0; k < cfg_.forced_inputs; k++) {
@@ -409,17 +410,16 @@ std::optional<Expr> Generator::gen_array_index(size_t) {
   // must be made to keep the random stream aligned with the reference.
   const std::vector<size_t>& arrays = scope_stack_.touched_list;
   const size_t n = arrays.size();
-  size_t chosen_pos = 0, chosen_idx = 0;
-  array_draws_.clear();
+  if (n == 0) return std::nullopt;
   // a position in 0..=written, not one of the written elements (generator.rs:584): it can
   // name an unwritten element, or one past the end when every element is written
   // rand(0, w) with w >= 1 always draws (an array is in the list once an element is written), and
-  // is next() % (w + 1): the stream advances once per array, the division is needed for one
-  for (size_t k = 0; k < n; k++) array_draws_.push_back(rng_.next());
-  if (n == 0) return std::nullopt;
+  // is next() % (w + 1): the stream advances once per array, and only the chosen array's draw is looked at
+  const Rng before = rng_;
+  rng_.skip(n);
   const size_t pick = rng_.rand(0, n - 1);
-  chosen_pos = arrays[pick];
-  chosen_idx = array_draws_[pick] % ((uint64_t)scope_stack_.written_count[chosen_pos] + 1);
+  const size_t chosen_pos = arrays[pick];
+  size_t chosen_idx = before.peek(pick) % ((uint64_t)scope_stack_.written_count[chosen_pos] + 1);
   const Variable& v = scope_stack_.flat[chosen_pos];
   if (cfg_.safe_array_index) {  // extension: always a written element
     const size_t written = v.initialized.count();

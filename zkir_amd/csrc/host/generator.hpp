@@ -99,7 +99,6 @@ class Generator {
   size_t n_instr_ = 0;
   ScopeStack scope_stack_;
   std::vector<Instruction> pending_;  // declarations an extension wants emitted before its statement
-  std::vector<size_t> array_draws_;   // scratch of gen_array_index
   size_t requested_ = 0, generated_ = 0;
 };
 
