@@ -139,6 +139,38 @@ def test_injected_fault_is_counted_and_located(ctx):
     ctx.release(tid)
 
 
+def test_checks_against_the_constant_one(ctx):
+    """`value * 1 == signal` (the constraint of a signal with a linear value): the kernels compare the left factor
+    as it is when the right factor is the pool's constant 1.  Every operand kind as left factor, satisfied vectors
+    and a few with one bit of the signal flipped, against the C checker (which multiplies by one)."""
+    ops = [(F.OP_INPUT, G(0), I(0), NONE), (F.OP_INPUT, L(0), I(1), NONE), (F.OP_INPUT, G(1), I(2), NONE),
+           (F.OP_CHECK, G(1), G(0), K(1)),              # device slot * 1 == device slot
+           (F.OP_CHECK, G(1), L(0), K(1)),              # LDS slot * 1
+           (F.OP_ADD, G(2), G(0), K(0)), (F.OP_CHECK, ACC, ACC, K(1)), (F.OP_CHECK, G(2), ACC, K(1)),
+           (F.OP_CHECK, ACC, G(2), K(1)),
+           (F.OP_CHECK, K(2), K(2), K(1)),              # a constant against itself
+           (F.OP_CHECK, G(1), G(0), K(2)),              # the same check against p - 1: a product, fails unless x = 0
+           (F.OP_MUL, G(3), G(0), K(1)), (F.OP_CHECK, G(1), G(3), K(1)), (F.OP_OUTPUT, 0, G(3), NONE)]
+    tape = hand_tape(ops, [77, 1, F.P - 1], 3, 1, 4, 1)
+    rnd = random.Random(31)
+    n = 3000
+    vecs = [[x, x, x] for x in (rnd.choice([0, 1, F.P - 1]) if rnd.random() < 0.1 else rnd.randrange(F.P) for _ in range(n))]
+    inp = z.pack_inputs(vecs, 3)
+    tid = ctx.upload(tape)
+    out, unsat, first, faults = ctx.eval_batch(tid, inp, n)
+    o_c, u_c, first_c, f_c = C.eval_cpu(bytes(tape.hdr), tape.blob(), inp, n, 1)
+    zeros = sum(1 for v in vecs if v[0] == 0)
+    assert np.array_equal(out, o_c) and (unsat, first, faults) == (u_c, first_c, f_c) and unsat == n - zeros
+    flipped = sorted(rnd.sample(range(n), 9))
+    for t in flipped:
+        inp[2, rnd.randrange(7), t] ^= 1 << rnd.randrange(32)  # limb 7 untouched: the value stays below p
+    out, unsat, first, faults = ctx.eval_batch(tid, inp, n)
+    o_c, u_c, first_c, f_c = C.eval_cpu(bytes(tape.hdr), tape.blob(), inp, n, 1)
+    assert np.array_equal(out, o_c) and (unsat, first, faults) == (u_c, first_c, f_c)
+    assert unsat >= n - zeros - 9 + 3 * len(flipped)
+    ctx.release(tid)
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1023])
 def test_batch_sizes_around_the_workgroup(ctx, n):
     c = z.Generator(11, ext_config(min_instructions=80, max_instructions=80, forced_inputs=3, inputs_readable=1,

@@ -15,6 +15,14 @@ from tests import isa_model as IM
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+
+def one_word_of(consts):
+    """Operand word of the constant 1 in a tape's pool, as the runtime finds it at upload (0xffffffff: none)."""
+    for i, c in enumerate(consts):
+        if c == 1:
+            return (2 << 29) | i
+    return 0xFFFFFFFF
+
 def _gen():
     spec = importlib.util.spec_from_file_location("gen_interp29_asm", os.path.join(ROOT, "tools", "gen_interp29_asm.py"))
     m = importlib.util.module_from_spec(spec)
@@ -94,7 +102,7 @@ def run_lane(ops, consts, inputs, n_outputs, n_lslots, n_gslots, vec, wave=0, la
     lds_base = TAB_BASE + TAB_BYTES + (SLOT if victim else 0)  # the victim row, if any, comes before the window
     xbase = lds_base + n_lslots * SLOT
     operands = {
-        "%[ops]": OPS_BASE, "%[n_ops]": len(ops), "%[consts]": CST_BASE, "%[n_consts]": len(consts),
+        "%[ops]": OPS_BASE, "%[n_ops]": len(ops), "%[consts]": CST_BASE, "%[n_consts]": len(consts), "%[one_word]": one_word_of(consts),
         "%[gslots]": gs, "%[gslot_bytes]": gs_bytes, "%[lds_base]": lds_base, "%[lds_tab]": TAB_BASE,
         "%[evict_below]": 0x20000000 if victim else 0,
         "%[in_base]": IN_BASE, "%[out_base]": OUT_BASE if want_outputs else 0,
@@ -292,6 +300,42 @@ def test_a_broken_witness_is_counted():
     assert got_out == want_out and unsat == len(want_unsat) and first == want_unsat[0]
 
 
+def test_check_against_the_constant_one_multiplies_nothing():
+    """`value * 1 == signal`: with the pool's 1 as right factor the left factor is compared as it is, from every
+    operand kind, holding and failing alike; the same checks against another constant run the product."""
+    rnd = random.Random(5)
+    NONE, ACC = O(F.K_NONE), O(F.K_ACC)
+
+    def tape(k):  # k: index of the right factor in the pool
+        return [
+            (F.OP_INPUT, O(F.K_LSLOT, 0), O(F.K_INPUT, 0), NONE),
+            (F.OP_INPUT, O(F.K_GSLOT, 0), O(F.K_INPUT, 1), NONE),
+            (F.OP_CHECK, O(F.K_GSLOT, 0), O(F.K_GSLOT, 0), O(F.K_CONST, k)),  # device slot against itself: holds
+            (F.OP_CHECK, O(F.K_LSLOT, 0), O(F.K_GSLOT, 0), O(F.K_CONST, k)),  # against the other input: fails
+            (F.OP_CHECK, O(F.K_LSLOT, 0), O(F.K_LSLOT, 0), O(F.K_CONST, k)),  # LDS slot: holds
+            (F.OP_COPY, NONE, O(F.K_LSLOT, 0), NONE),
+            (F.OP_CHECK, ACC, ACC, O(F.K_CONST, k)),                          # accumulator against itself: holds
+            (F.OP_CHECK, O(F.K_GSLOT, 0), ACC, O(F.K_CONST, k)),              # accumulator against the other: fails
+            (F.OP_CHECK, ACC, O(F.K_LSLOT, 0), O(F.K_CONST, k)),              # holds
+            (F.OP_CHECK, O(F.K_CONST, 2), O(F.K_CONST, 2), O(F.K_CONST, k)),  # constant: holds
+            (F.OP_MUL, NONE, O(F.K_GSLOT, 0), O(F.K_CONST, k)),               # a product by 1 is still a product
+            (F.OP_CHECK, ACC, O(F.K_GSLOT, 0), O(F.K_CONST, k)),              # holds, with the slot still in the a registers
+            (F.OP_OUTPUT, 0, O(F.K_GSLOT, 0), NONE),
+        ]
+    inputs = [[rnd.randrange(F.P), rnd.randrange(F.P)] for _ in range(66)]
+    inputs[1] = [F.P - 1, 0]
+    picks = [(0, 0, 0, True), (1, 1, 1, True), (65, 2, 40, True), (9, 3, 63, False)]
+    consts = [7, 1, F.P - 1]
+    check_tape(tape(1), consts, inputs, 1, 1, 1, picks)
+    # the same tape with the 1 in a pool that holds it at another place, and in a pool that holds none: x * 7
+    check_tape(tape(0), [1, 5, 9], inputs, 1, 1, 1, picks)
+    check_tape(tape(0), consts, inputs, 1, 1, 1, picks)
+    _, unsat, first, by_one = run_lane(tape(1), consts, inputs, 1, 1, 1, 0)
+    assert (unsat, first) == (2, 1)
+    _, _, _, by_seven = run_lane(tape(0), consts, inputs, 1, 1, 1, 0)
+    assert by_one.steps < by_seven.steps - 7 * 150  # seven products not made
+
+
 def test_inc_file_is_current():
     path = os.path.join(ROOT, "zkir_amd", "csrc", "hip", "interp29_core_asm.inc")
     assert open(path).read() == G.render(G.build()), "run tools/gen_interp29_asm.py"
@@ -363,7 +407,7 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
     lanes, pcs, begin = [], [], 0
     for w in range(n_str):
         operands = {
-            "%[ops]": OPS_BASE + 16 * begin, "%[n_ops]": strand_ops[w], "%[consts]": CST_BASE, "%[n_consts]": len(consts),
+            "%[ops]": OPS_BASE + 16 * begin, "%[n_ops]": strand_ops[w], "%[consts]": CST_BASE, "%[n_consts]": len(consts), "%[one_word]": one_word_of(consts),
             "%[gslots]": GS_BASE + (w >> 2) * gs_bytes, "%[gslot_bytes]": gs_bytes,
             "%[lds_base]": lds_rows + (w >> 2) * n_lslots * SLOT, "%[lds_tab]": TAB_BASE, "%[evict_below]": 0,
             "%[in_base]": IN_BASE, "%[out_base]": OUT_BASE, "%[n4]": 4 * n_vec, "%[live]": 0x8000000000000001 | (1 << lane),

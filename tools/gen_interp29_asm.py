@@ -110,6 +110,7 @@ IN_EVICT = "%[evict_below]"  # 0x20000000 when the launch has a victim row, 0 wh
 IN_XBASE, IN_VX = "%[xbase]", "%[v_x]"  # strand tapes: LDS address of the exchange slots, lane * 16
 IN_VLO4, IN_VX4 = "%[v_lo4]", "%[v_x4]"  # plane 2 of a slot: wave * 2304 + 2048 + lane * 4; 2048 + lane * 4
 IN_TAB = "%[lds_tab]"  # LDS address of the table of q * p, 48 bytes per entry, q < 32
+IN_ONE = "%[one_word]"  # the operand word of the tape's constant 1 (0xffffffff when its pool holds none)
 IN_ROT = "%[rot]"      # which of the workgroups resident on its CU this one is (0..3): the phase of its priority
                        # turns; -1: no turns
 IN_ROTSH = "%[rot_shift]"  # a turn lasts 1 << rot_shift ticks of the 100 MHz clock
@@ -349,6 +350,14 @@ def build():
     a.e("s_cmp_lt_u32 %s, 16" % CODE)
     a.e("s_cbranch_scc1 .Lz29_unary")
 
+    # A CHECK whose right factor is the constant 1 (the constraint of a signal with a linear value, `value * 1 ==
+    # signal`) multiplies nothing: the left factor goes into the comparison as it is (x * 1 = x mod p, and the
+    # comparison is one modulo p).
+    a.e("s_cmp_eq_u32 %s, %s" % (OP[3], IN_ONE))
+    a.e("s_cbranch_scc0 .Lz29_b_not_one")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_CHECK))
+    a.e("s_cbranch_scc1 .Lz29_check_one")
+    a.label(".Lz29_b_not_one")
     # binary ops and CHECK: fetch b, then a (or note that a is the accumulator)
     fetch(a, OP[3], VBB, AD_B, stem="b", tag=TAG_B)
     a.e("s_mov_b32 %s, 0" % AACC)
@@ -408,8 +417,16 @@ def build():
     a.e("s_branch .Lz29_check_cmp")
     a.label(".Lz29_check_acc")
     mul_stream(a, ACC9, B9, A9)
+    a.e("s_branch .Lz29_check_cmp")
+    a.label(".Lz29_check_one")  # the "product" is the left factor: into the a registers as any operand would be
+    fetch(a, OP[2], VA, AD_A, acc_label=".Lz29_one_acc", stem="p", tag=TAG_A)
+    wait_loads(a)
+    a.e("s_branch .Lz29_check_cmp")
+    a.label(".Lz29_one_acc")
+    for j in range(9):
+        a.e("v_mov_b32 %s, %s" % (A9[j], ACC9[j]))
     a.label(".Lz29_check_cmp")
-    a.e("s_mov_b32 %s, -1" % TAG_A)  # the a registers now hold the product
+    a.e("s_mov_b32 %s, -1" % TAG_A)  # the a registers now hold the product (the comparison below works in place)
     a.e("s_mov_b32 %s, 0" % VMF)
     fetch(a, OP[1], VBB, AD_C, acc_label=".Lz29_cmp_acc", stem="c", tag=TAG_B)
     wait_loads(a)

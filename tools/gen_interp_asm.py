@@ -113,6 +113,7 @@ IN_N4, IN_LIVE = "%[n4]", "%[live]"
 IN_VLO, IN_VVEC = "%[v_lo]", "%[v_vec4]"
 IN_EVICT = "%[evict_below]"  # 0x20000000 when the launch has a victim row, 0 when it has none
 IN_XBASE, IN_VX = "%[xbase]", "%[v_x]"  # strand tapes: LDS address of the exchange slots, lane * 16
+IN_ONE = "%[one_word]"  # the operand word of the tape's constant 1 (0xffffffff when its pool holds none)
 OUT_UNSAT, OUT_FIRST = "%[unsat]", "%[first]"
 
 
@@ -372,6 +373,13 @@ def build():
     a.e("s_cmp_lt_u32 %s, 16" % CODE)
     a.e("s_cbranch_scc1 .Lzk_unary")
 
+    # A CHECK whose right factor is the constant 1 (the constraint of a signal with a linear value, `value * 1 ==
+    # signal`) multiplies nothing: the left factor is compared as it is.  x * 1 is x bit for bit, so no result changes.
+    a.e("s_cmp_eq_u32 %s, %s" % (OP[3], IN_ONE))
+    a.e("s_cbranch_scc0 .Lzk_b_not_one")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_CHECK))
+    a.e("s_cbranch_scc1 .Lzk_check_one")
+    a.label(".Lzk_b_not_one")
     # binary ops and CHECK: fetch b, then a (or note that a is the accumulator)
     fetch(a, OP[3], VBB, AD_B, stem="b", tag=TAG_B)
     a.e("s_mov_b32 %s, 0" % AACC)
@@ -428,8 +436,17 @@ def build():
     a.e("s_branch .Lzk_check_cmp")
     a.label(".Lzk_check_acc")
     mul_stream(a, ACC8, B8, A8)
+    a.e("s_branch .Lzk_check_cmp")
+    a.label(".Lzk_check_one")  # the "product" is the left factor: into the a registers as any operand would be
+    fetch(a, OP[2], VA, AD_A, acc_label=".Lzk_one_acc", stem="p", tag=TAG_A)
+    wait_loads(a)
+    a.e("s_branch .Lzk_check_cmp_keep")  # the a registers hold what their tag says
+    a.label(".Lzk_one_acc")
+    for j in range(8):
+        a.e("v_mov_b32 %s, %s" % (A8[j], ACC8[j]))
     a.label(".Lzk_check_cmp")
     a.e("s_mov_b32 %s, -1" % TAG_A)  # the a registers now hold the product
+    a.label(".Lzk_check_cmp_keep")
     a.e("s_mov_b32 %s, 0" % VMF)
     fetch(a, OP[1], VBB, AD_C, acc_label=".Lzk_cmp_acc", stem="c", tag=TAG_B)
     wait_loads(a)

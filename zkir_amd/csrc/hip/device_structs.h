@@ -8,7 +8,7 @@
 
 namespace zkir {
 
-// Device-side description of one uploaded tape (136 bytes, read with scalar loads).
+// Device-side description of one uploaded tape (144 bytes, read with scalar loads).
 struct TapeDesc {
   const zkir_op* ops;      // n_ops entries
   const uint32_t* consts;  // n_consts x 8 limbs, Montgomery form
@@ -25,7 +25,10 @@ struct TapeDesc {
   uint32_t strand_begin[ZKIR_MAX_STRANDS];  // strand tapes: first op of each strand
   uint32_t strand_ops[ZKIR_MAX_STRANDS];    // strand tapes: ops of each strand
   const uint32_t* consts29;             // n_consts x 12 words: 9 limbs of 29 bits, Montgomery form with R = 2^261
+  uint32_t one_word;       // operand word of the constant 1 in this tape's pool (0xffffffff: none): a CHECK whose
+                           // right factor is that word compares its left factor as it is
+  uint32_t reserved;
 };
-static_assert(sizeof(TapeDesc) == 136, "TapeDesc layout");
+static_assert(sizeof(TapeDesc) == 144, "TapeDesc layout");
 
 }  // namespace zkir

@@ -282,7 +282,9 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
         store_operand(op.dst, acc, cx);
       } else if (code == ZKIR_OP_CHECK) {
         Fr t;
-        if (a_acc) {
+        if (op.b == td.one_word) {  // value * 1 == signal: the left factor as it is (x * 1 is x bit for bit)
+          t = load_operand(op.a, acc, cx);
+        } else if (a_acc) {
           const Fr y = load_operand(op.b, acc, cx);
           t = fr_mul(acc, y);
         } else {
@@ -411,7 +413,7 @@ zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, ui
                  : [ops] "s"(ops), [n_ops] "s"(n_ops), [consts] "s"(consts), [n_consts] "s"(td.n_consts),
                    [gslots] "s"(gslots), [gslot_bytes] "s"(gslot_bytes), [lds_base] "s"(lds_base),
                    [in_base] "s"(in_base), [out_base] "s"(out_base), [n4] "s"(n4), [live] "s"(live_mask),
-                   [evict_below] "s"(evict_below), [xbase] "s"(xbase), [v_lo] "v"(v_lo), [v_vec4] "v"(v_vec4), [v_x] "v"(v_x)
+                   [evict_below] "s"(evict_below), [xbase] "s"(xbase), [one_word] "s"(td.one_word), [v_lo] "v"(v_lo), [v_vec4] "v"(v_vec4), [v_x] "v"(v_x)
                  : ZKIR_INTERP_CORE_CLOBBERS);
 
     if (lane == 0 && wave_unsat)
@@ -501,7 +503,7 @@ zkir_interp_lean29_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, 
                  : [ops] "s"(ops), [n_ops] "s"(n_ops), [consts] "s"(consts), [n_consts] "s"(td.n_consts),
                    [gslots] "s"(gslots), [gslot_bytes] "s"(gslot_bytes), [lds_base] "s"(lds_base), [lds_tab] "s"(lds_tab),
                    [in_base] "s"(in_base), [out_base] "s"(out_base), [n4] "s"(n4), [live] "s"(live_mask),
-                   [evict_below] "s"(evict_below), [xbase] "s"(xbase), [rot] "s"(rot), [rot_shift] "s"(rot_shift), [v_lo] "v"(v_lo), [v_lo4] "v"(v_lo4),
+                   [evict_below] "s"(evict_below), [xbase] "s"(xbase), [one_word] "s"(td.one_word), [rot] "s"(rot), [rot_shift] "s"(rot_shift), [v_lo] "v"(v_lo), [v_lo4] "v"(v_lo4),
                    [v_vec4] "v"(v_vec4), [v_x] "v"(v_x), [v_x4] "v"(v_x4)
                  : ZKIR_INTERP29_CORE_CLOBBERS);
 

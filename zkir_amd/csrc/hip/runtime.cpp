@@ -42,6 +42,7 @@ struct DevTape {
   void* consts = nullptr;  // device, Montgomery form (8 x 32-bit limbs, R = 2^256)
   void* consts29 = nullptr;  // device, the same constants as 9 x 29-bit limbs with R = 2^261, 12 words each
   void* desc = nullptr;    // device: the TapeDesc of this tape evaluated alone (offsets 0, unsat index 0)
+  uint32_t one_word = 0xffffffffu;  // operand word of the constant 1 in the tape's pool, if it holds one
   int slab = -1;           // which slab of the context's tape arena holds ops, consts and desc
 };
 
@@ -191,6 +192,7 @@ TapeDesc make_desc(const DevTape& t, uint32_t index, uint64_t in_off, uint64_t o
   d.ops = (const zkir_op*)t.ops;
   d.consts = (const uint32_t*)t.consts;
   d.consts29 = (const uint32_t*)t.consts29;
+  d.one_word = t.one_word;
   d.in_word_off = in_off;
   d.out_word_off = out_off;
   d.n_ops = t.hdr.n_ops;
@@ -557,6 +559,14 @@ int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hd
     DevTape& t = tapes[k];
     t.hdr = hdrs[k];
     t.full = tape_is_full(hdrs[k], blobs[k]);
+    {  // which constant, if any, is 1 (the pool of a lowered tape holds every value once; the first match is taken)
+      const uint32_t* cw = (const uint32_t*)((const char*)blobs[k] + (size_t)hdrs[k].n_ops * sizeof(zkir_op));
+      for (uint32_t c = 0; c < hdrs[k].n_consts && t.one_word == 0xffffffffu; c++) {
+        uint32_t rest = 0;
+        for (int l = 1; l < 8; l++) rest |= cw[(size_t)c * 8 + l];
+        if (cw[(size_t)c * 8] == 1u && rest == 0) t.one_word = ZKIR_OPERAND(ZKIR_KIND_CONST, c);
+      }
+    }
     if (t.full && (hdrs[k].flags & ZKIR_TAPE_F_STRANDS))
       return fail(ctx, ZKIR_E_INVALID, "bad tape: strand tapes are made of + - * and data movement only");
     ops_total += (size_t)hdrs[k].n_ops * sizeof(zkir_op);
