@@ -253,6 +253,36 @@ def test_check_against_the_constant_one_multiplies_nothing():
     assert by_one.steps < by_seven.steps - 7 * 150  # seven products not made
 
 
+def test_operands_of_the_next_op_are_sent_for_inside_a_product():
+    """Inside the product of a MUL, and of a CHECK whose right-hand side is the accumulator, the stream sends for the
+    next op's a and b operands; that op finds them by their tags and waits for them.  Not when the next op reads what
+    this op is about to store, and never for the last op.  Same results, and no load is issued twice."""
+    rnd = random.Random(21)
+    NONE, ACC = O(F.K_NONE), O(F.K_ACC)
+    G = lambda i: O(F.K_GSLOT, i)
+    head = [(F.OP_INPUT, G(i), O(F.K_INPUT, i), NONE) for i in range(5)]
+    ops = head + [
+        (F.OP_MUL, G(5), G(0), G(1)),      # sends for G2, G3 (the next op's operands)
+        (F.OP_MUL, G(6), G(2), G(3)),      # next op reads G6 = this op's destination: nothing sent for
+        (F.OP_ADD, NONE, G(6), G(4)),
+        (F.OP_OUTPUT, 0, ACC, NONE),
+        (F.OP_MUL, NONE, G(0), G(4)),      # a is not in the registers any more, b is; sends for G5 and G1
+        (F.OP_CHECK, ACC, G(1), G(5)),     # wrong on purpose; right-hand side in the accumulator: sends for G2 (b) and G6 (a)
+        (F.OP_SUB, NONE, G(6), G(2)),
+        (F.OP_OUTPUT, 1, ACC, NONE),
+        (F.OP_MUL, G(7), ACC, G(3)),       # the next op is unary: nothing sent for
+        (F.OP_OUTPUT, 2, G(7), NONE),
+        (F.OP_MUL, NONE, G(7), G(7)),      # the last op
+    ]
+    inputs = [[rnd.randrange(F.P) for _ in range(5)] for _ in range(3)]
+    check_tape(ops, [], inputs, 3, 0, 8, [(0, 0, 0, True), (2, 3, 63, True), (1, 1, 7, False)])
+    _, unsat, first, ln = run_lane(ops, [], inputs, 3, 0, 8, 1, victim=False)
+    assert unsat == 1 and first == 0
+    # values loaded from device slots: G0 G1 | G2 G3 | G6 G4 | G0 | G5 G1 | G2 G6 | G3 | G7 (OUTPUT, into the a
+    # registers) | G7 as b of the last MUL (its a is found in the a registers): no value is loaded twice in a row
+    assert ln.counts["buffer_load_dwordx4"] == 2 * 14
+
+
 def test_inc_file_is_current():
     path = os.path.join(ROOT, "zkir_amd", "csrc", "hip", "interp_core_asm.inc")
     assert open(path).read() == G.render(G.build()), "run tools/gen_interp_asm.py"
@@ -324,12 +354,12 @@ def test_operand_registers_are_reused_and_invalidated():
     head = [(F.OP_INPUT, G0, O(F.K_INPUT, 0), NONE), (F.OP_INPUT, G1, O(F.K_INPUT, 1), NONE),
             (F.OP_INPUT, G2, O(F.K_INPUT, 2), NONE)]
     reuse = head + [
-        (F.OP_MUL, L0, G0, G1),          # loads G0, G1
-        (F.OP_ADD, NONE, ACC, G2),       # loads G2 into the b registers
+        (F.OP_MUL, L0, G0, G1),          # loads G0, G1; inside the product G2 is sent for (the next op's b)
+        (F.OP_ADD, NONE, ACC, G2),       # finds G2 in the b registers
         (F.OP_OUTPUT, 0, ACC, NONE),
         (F.OP_SUB, NONE, ACC, G2),       # b is still there
         (F.OP_CHECK, ACC, G0, G1),       # a is still there, b is reloaded
-        (F.OP_CHECK, L0, G0, G1),        # a was overwritten by the product, b still there; c (L0) replaces b
+        (F.OP_CHECK, L0, G0, G1),        # a and b still there (the product went to scratch registers); c (L0) replaces b
         (F.OP_MUL, NONE, O(F.K_CONST, 0), L0),  # L0 sits in the b registers
         (F.OP_OUTPUT, 1, ACC, NONE),
     ]
@@ -338,14 +368,14 @@ def test_operand_registers_are_reused_and_invalidated():
     want_out, want_unsat = oracle(reuse, consts, inputs[1], 2)
     got_out, unsat, first, ln = run_lane(reuse, consts, inputs, 2, 1, 3, 1, lane=3)
     assert got_out == want_out and unsat == len(want_unsat) == 0
-    # device-slot loads: G0, G1, G2, then G0 again for the second CHECK = 4 values = 8 instructions;
+    # device-slot loads: G0, G1, G2 = 3 values = 6 instructions;
     # G1 for the first CHECK comes back from the victim row, where G2's arrival had pushed it
-    assert ln.counts["buffer_load_dwordx4"] == 8
+    assert ln.counts["buffer_load_dwordx4"] == 6
     assert ln.counts["ds_read_b128"] == 4  # G1 from the victim row, L0 as c of the second CHECK
     # without a victim row (launches with a large window) G1 is loaded again, and LDS holds the window only
     got_out, unsat, first, ln = run_lane(reuse, consts, inputs, 2, 1, 3, 1, lane=3, victim=False)
     assert got_out == want_out and unsat == 0
-    assert ln.counts["buffer_load_dwordx4"] == 10 and ln.counts["ds_read_b128"] == 2 and "ds_write_b128" in ln.counts
+    assert ln.counts["buffer_load_dwordx4"] == 8 and ln.counts["ds_read_b128"] == 2 and "ds_write_b128" in ln.counts
 
     stale = head + [
         (F.OP_MUL, NONE, G0, G1),

@@ -134,14 +134,18 @@ class Asm:
 
 
 # ---- arithmetic streams -----------------------------------------------------
-def mul_stream(a, x, y, r):
-    """r = x*y*2^-256 mod p, below p, for x, y below p; x, y, r lists of 8 registers; r may alias x or y.
+def mul_stream(a, x, y, r, after_unpack=None):
+    """r = x*y*2^-256 mod p, below p, for x, y below p; x, y, r lists of 8 registers; r may alias x or y, or be W8.
+    after_unpack: called once x and y have been read for the last time (the registers of x and y are free from
+    there on unless r names them): the place where the next op's operands are sent for.
     The 8 x 32-bit operands are unpacked to 9 limbs of 29 bits, x as 32 x, and multiplied with the radix-2^261
     Montgomery product of tools/fr29.py (162 multiply-adds into 64-bit column sums and no add that writes a carry:
     on gfx950 such an add costs an issue slot like a multiply): 32 x y 2^-261 = x y 2^-256.  The result, below
     1.3 p with limbs below 2^29, is packed back to 8 words and p is subtracted once if it fits."""
     fr29.unpack29(a.lines, UA, x, times32=True)
     fr29.unpack29(a.lines, UB, y)
+    if after_unpack:
+        after_unpack()
     fr29.mul29(a.lines, UA, UB, M9, M9, ACCN, SP29, SNP29, CS)
     fr29.pack29(a.lines, W8, M9, TT)
     a.e("v_sub_co_u32 %s, vcc, %s, %s" % (T8[0], W8[0], P8[0]))
@@ -212,10 +216,11 @@ def sub_stream(a, x, y, r):
 
 
 # ---- operand access ----------------------------------------------------------
-def fetch(a, sop, dst_base, addr, acc_label=None, stem="f", tag=None):
+def fetch(a, sop, dst_base, addr, acc_label=None, stem="f", tag=None, vmf=1):
     """Issue the loads of the operand word in SGPR `sop` into v[dst_base..+7].
     kind ACC: jump to acc_label if given (nothing loaded), else copy the accumulator.
-    Device-slot loads set VMF so the caller knows to wait on vmcnt.
+    Device-slot loads set VMF so the caller knows to wait on vmcnt (vmf = 1: this op's loads; 2: loads sent for
+    ahead of time for the next op, which becomes 1 when that op begins).
     tag: the SGPR that remembers which operand word these registers hold; when it equals
     `sop` the value is already there (no op stored to that slot since: stores reset the tag)
     and nothing is loaded."""
@@ -294,7 +299,7 @@ def fetch(a, sop, dst_base, addr, acc_label=None, stem="f", tag=None):
     a.e("v_add_u32 %s, %s, %s" % (addr, T1, IN_VLO))
     a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen" % (quad(dst_base, 0), addr, D_GS))
     a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:1024" % (quad(dst_base, 1), addr, D_GS))
-    a.e("s_mov_b32 %s, 1" % VMF)
+    a.e("s_mov_b32 %s, %d" % (VMF, vmf))
     a.e("s_branch %s" % l_done)
     a.label(l_lds)
     if tag:
@@ -320,9 +325,43 @@ def wait_loads(a):
     device-slot load was issued (stores of earlier ops stay in flight otherwise)."""
     skip = a.new("wskip")
     a.e("s_waitcnt lgkmcnt(0)")
-    a.e("s_cmp_eq_u32 %s, 0" % VMF)
-    a.e("s_cbranch_scc1 %s" % skip)
+    a.e("s_and_b32 %s, %s, 1" % (T0, VMF))
+    a.e("s_cbranch_scc0 %s" % skip)
     a.e("s_waitcnt vmcnt(0)")
+    a.label(skip)
+
+
+NXW = ["s%d" % (SB + 20 + k) for k in range(4)]  # the next op: code, dst, a, b
+
+
+def prefetch_next(a, stem, host_is_check):
+    """Inside a product, once its operands are unpacked: if the next op is a binary op or a CHECK, send for its b
+    and a operands now (same fetch as that op would make, into the same registers, with the same tags and the same
+    use of the victim row), so that device-memory latency passes behind the product.  The next op then finds its
+    operands by their tags and waits for them (VMF bit 1 becomes bit 0 at its start).
+    Not done: for the last op; when the next op reads what this op is about to store; when the next op is a CHECK
+    against the constant 1 (it fetches no b); inside a CHECK whose right-hand side is not the accumulator (it is
+    fetched into the b registers after the product)."""
+    skip, after_b = a.new(stem + "skip"), a.new(stem + "ab")
+    a.e("s_waitcnt lgkmcnt(0)")  # the next op has arrived
+    a.e("s_cmp_eq_u32 %s, 0" % REM)
+    a.e("s_cbranch_scc1 %s" % skip)
+    if host_is_check:
+        a.e("s_lshr_b32 %s, %s, 29" % (T3, OP[1]))
+        a.e("s_cmp_eq_u32 %s, %d" % (T3, K_ACC))
+        a.e("s_cbranch_scc0 %s" % skip)
+    a.e("s_and_b32 %s, %s, 0xff" % (T3, NXW[0]))
+    a.e("s_cmp_lt_u32 %s, 16" % T3)
+    a.e("s_cbranch_scc1 %s" % skip)
+    a.e("s_cmp_eq_u32 %s, %s" % (NXW[3], IN_ONE))
+    a.e("s_cbranch_scc1 %s" % skip)
+    if not host_is_check:
+        for w in (NXW[3], NXW[2]):
+            a.e("s_cmp_eq_u32 %s, %s" % (w, OP[1]))
+            a.e("s_cbranch_scc1 %s" % skip)
+    fetch(a, NXW[3], VBB, AD_B, acc_label=after_b, stem=stem + "b", tag=TAG_B, vmf=2)
+    a.label(after_b)
+    fetch(a, NXW[2], VA, AD_A, acc_label=skip, stem=stem + "a", tag=TAG_A, vmf=2)
     a.label(skip)
 
 
@@ -348,6 +387,7 @@ def build():
     a.e("s_mov_b32 %s, -1" % TAG_A)
     a.e("s_mov_b32 %s, -1" % TAG_B)
     a.e("s_mov_b32 %s, -1" % TAG_V)
+    a.e("s_mov_b32 %s, 0" % VMF)
     a.e("s_mov_b64 %s, 0" % UNSAT)
     a.e("s_mov_b32 %s, 0" % KCHK)
     a.e("s_mov_b32 %s, 0x%08x" % (SNP0, NP0))
@@ -369,7 +409,7 @@ def build():
     a.e("s_add_u32 %s, %s, 16" % (PCOFF, PCOFF))
     a.label(".Lzk_nopf")
     a.e("s_and_b32 %s, %s, 0xff" % (CODE, OP[0]))
-    a.e("s_mov_b32 %s, 0" % VMF)
+    a.e("s_lshr_b32 %s, %s, 1" % (VMF, VMF))  # loads sent for during the last op are this op's loads now
     a.e("s_cmp_lt_u32 %s, 16" % CODE)
     a.e("s_cbranch_scc1 .Lzk_unary")
 
@@ -403,10 +443,10 @@ def build():
     a.e("s_cmp_eq_u32 %s, 1" % AACC)
     a.e("s_cbranch_scc1 .Lzk_mul_acc")
     a.label(".Lzk_mul_ab")
-    mul_stream(a, A8, B8, ACC8)
+    mul_stream(a, A8, B8, ACC8, after_unpack=lambda: prefetch_next(a, "pm", False))
     a.e("s_branch .Lzk_store")
     a.label(".Lzk_mul_acc")
-    mul_stream(a, ACC8, B8, ACC8)
+    mul_stream(a, ACC8, B8, ACC8, after_unpack=lambda: prefetch_next(a, "pn", False))
     a.e("s_branch .Lzk_store")
 
     a.label(".Lzk_add")
@@ -428,37 +468,37 @@ def build():
     sub_stream(a, ACC8, B8, ACC8)
     a.e("s_branch .Lzk_store")
 
-    # CHECK: product into the a registers, then compare with c
+    # CHECK: product into scratch registers (the a and b registers keep what their tags say), then compare with c
     a.label(".Lzk_check")
     a.e("s_cmp_eq_u32 %s, 1" % AACC)
     a.e("s_cbranch_scc1 .Lzk_check_acc")
-    mul_stream(a, A8, B8, A8)
+    mul_stream(a, A8, B8, W8, after_unpack=lambda: prefetch_next(a, "pc", True))
     a.e("s_branch .Lzk_check_cmp")
     a.label(".Lzk_check_acc")
-    mul_stream(a, ACC8, B8, A8)
+    mul_stream(a, ACC8, B8, W8, after_unpack=lambda: prefetch_next(a, "pd", True))
     a.e("s_branch .Lzk_check_cmp")
-    a.label(".Lzk_check_one")  # the "product" is the left factor: into the a registers as any operand would be
+    a.label(".Lzk_check_one")  # the "product" is the left factor
     fetch(a, OP[2], VA, AD_A, acc_label=".Lzk_one_acc", stem="p", tag=TAG_A)
     wait_loads(a)
-    a.e("s_branch .Lzk_check_cmp_keep")  # the a registers hold what their tag says
+    for j in range(8):
+        a.e("v_mov_b32 %s, %s" % (W8[j], A8[j]))
+    a.e("s_branch .Lzk_check_cmp")
     a.label(".Lzk_one_acc")
     for j in range(8):
-        a.e("v_mov_b32 %s, %s" % (A8[j], ACC8[j]))
+        a.e("v_mov_b32 %s, %s" % (W8[j], ACC8[j]))
     a.label(".Lzk_check_cmp")
-    a.e("s_mov_b32 %s, -1" % TAG_A)  # the a registers now hold the product
-    a.label(".Lzk_check_cmp_keep")
-    a.e("s_mov_b32 %s, 0" % VMF)
+    a.e("s_and_b32 %s, %s, 2" % (VMF, VMF))  # this op's loads have been waited for; loads for the next op may be under way
     fetch(a, OP[1], VBB, AD_C, acc_label=".Lzk_cmp_acc", stem="c", tag=TAG_B)
     wait_loads(a)
 
     def compare(c):
-        a.e("v_xor_b32 %s, %s, %s" % (VT0, A8[0], c[0]))
-        a.e("v_xor_b32 %s, %s, %s" % (VT1, A8[1], c[1]))
+        a.e("v_xor_b32 %s, %s, %s" % (VT0, W8[0], c[0]))
+        a.e("v_xor_b32 %s, %s, %s" % (VT1, W8[1], c[1]))
         for j in range(2, 8, 2):
-            a.e("v_xor_b32 %s, %s, %s" % (E(0), A8[j], c[j]))
-            a.e("v_xor_b32 %s, %s, %s" % (E(1), A8[j + 1], c[j + 1]))
+            a.e("v_xor_b32 %s, %s, %s" % (E(0), W8[j], c[j]))
+            a.e("v_xor_b32 %s, %s, %s" % (M, W8[j + 1], c[j + 1]))
             a.e("v_or_b32 %s, %s, %s" % (VT0, VT0, E(0)))
-            a.e("v_or_b32 %s, %s, %s" % (VT1, VT1, E(1)))
+            a.e("v_or_b32 %s, %s, %s" % (VT1, VT1, M))
         a.e("v_or_b32 %s, %s, %s" % (VT0, VT0, VT1))
         a.e("s_nop 0")
         a.e("v_cmp_ne_u32 vcc, 0, %s" % VT0)

@@ -11,8 +11,9 @@ K_GSLOT, K_LSLOT, K_CONST, K_INPUT, K_ACC, K_NONE, K_XSLOT = range(7)
 OP_INPUT, OP_OUTPUT, OP_COPY, OP_NEG, OP_BARRIER, OP_CHECK = 1, 2, 3, 4, 7, 48
 
 
-def slot_traffic(ops, victim=True):
-    """(device-slot reads, device-slot writes, LDS window reads) for one vector."""
+def slot_traffic(ops, victim=True, one_word=-1):
+    """(device-slot reads, device-slot writes, LDS window reads) for one vector.
+    one_word: operand word of the tape's constant 1 (a CHECK against it fetches no b)."""
     tag = {"a": -1, "b": -1, "v": -1}
     reads = writes = lds = 0
 
@@ -53,9 +54,9 @@ def slot_traffic(ops, victim=True):
             fetch(a, "b")
             tag["a"] = -1
         elif code == OP_CHECK:
-            fetch(b, "b")
-            fetch(a, "a")
-            tag["a"] = -1
+            if b != one_word:
+                fetch(b, "b")
+            fetch(a, "a")  # the product goes to scratch registers: a and b keep their values
             fetch(dst, "b")
             continue
         else:
@@ -80,7 +81,9 @@ if __name__ == "__main__":
     args = ap.parse_args()
     t = bench.workload_tape(z, args.signal_window, args.linear_terms)
     h = t.hdr
-    r, w, l = slot_traffic(t.ops(), victim=not args.no_victim and h.n_lslots + 1 <= 4)
+    one = next((i for i, c in enumerate(t.consts()) if c == 1), None)
+    r, w, l = slot_traffic(t.ops(), victim=not args.no_victim and h.n_lslots + 1 <= 4,
+                           one_word=-1 if one is None else (K_CONST << 29) | one)
     per_vec = 32 * (r + w + h.n_inputs + h.n_outputs)
     print("ops %d, device slots %d, window slots %d: %d device-slot reads, %d writes, %d LDS reads per vector; "
           "%.1f KB per vector with inputs and outputs (%.1f GB per 2^20 vectors)"

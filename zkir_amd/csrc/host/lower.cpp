@@ -896,7 +896,7 @@ StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uin
 // Device-slot reads and writes of a tape per input vector, as the generated-stream kernels perform them: their operand
 // registers remember which operand word they hold (a and b), a device-slot value pushed out of them waits in one
 // victim row of LDS, a store to a slot makes every copy of it stale (zkir_interp_lean_kernel, tools/gen_interp_asm.py).
-uint64_t device_slot_traffic(const std::vector<zkir_op>& ops) {
+uint64_t device_slot_traffic(const std::vector<zkir_op>& ops, uint32_t one_word) {
   uint32_t tag_a = UINT32_MAX, tag_b = UINT32_MAX, tag_v = UINT32_MAX;
   uint64_t n = 0;
   auto fetch = [&](uint32_t word, uint32_t* tag) {
@@ -928,9 +928,8 @@ uint64_t device_slot_traffic(const std::vector<zkir_op>& ops) {
       fetch(op.a, &tag_b);
       tag_a = UINT32_MAX;
     } else if (code == ZKIR_OP_CHECK) {
-      fetch(op.b, &tag_b);
-      fetch(op.a, &tag_a);
-      tag_a = UINT32_MAX;
+      if (op.b != one_word) fetch(op.b, &tag_b);  // against the constant 1 nothing is multiplied and no b is fetched
+      fetch(op.a, &tag_a);                       // (the product goes to scratch registers: a and b keep their values)
       fetch(op.dst, &tag_b);
       continue;
     } else {
@@ -1727,12 +1726,15 @@ Tape Lowerer::lower() {
   StreamOut so;
   uint64_t best_cost = UINT64_MAX;
   std::vector<uint32_t> best_triples;
+  uint32_t one_word = UINT32_MAX;  // the pool's constant 1, as the runtime finds it at upload
+  for (size_t c = 0; c < p1.consts.size() && one_word == UINT32_MAX; c++)
+    if (p1.consts[c] == U256::from_u64(1)) one_word = ZKIR_OPERAND(ZKIR_KIND_CONST, c);
   const size_t lookaheads[3] = {0, 16, SIZE_MAX};
   for (int k = 0; k < (reorder ? 3 : 1); k++) {
     if (k) stream = schedule_statements(ops, p1.stmt_begin, nv, lookaheads[k]);
     StreamOut cand = opts_.window_cache ? place_stream_cached(ops, stream, nv, check_id, reorder, opts_, &triples)
                                         : place_stream(ops, stream, nv, {}, check_id, reorder, opts_, &triples);
-    const uint64_t cost = device_slot_traffic(cand.ops) * 4096ull + std::min<uint32_t>(cand.n_g, 4095u);
+    const uint64_t cost = device_slot_traffic(cand.ops, one_word) * 4096ull + std::min<uint32_t>(cand.n_g, 4095u);
     if (cost < best_cost) {
       best_cost = cost;
       so = std::move(cand);
