@@ -140,7 +140,10 @@ typedef enum zkir_opcode {
   ZKIR_OP_SHR = 33,  /* circom.rs:144-150 */
   ZKIR_OP_SHL = 34,  /* circom.rs:151-157 */
   /* constraint: count (vector, constraint) pairs with w[a]*w[b] != w[dst]
-     (`<==`, circom.rs:201-214); the k-th CHECK op of a tape is constraint k */
+     (`<==`, circom.rs:201-214); the k-th CHECK op of a tape is constraint k.
+     When b is the tape's constant 1 (lower writes the constraint of a signal
+     whose value is linear as `value * 1 == signal`) the device compares w[a]
+     with w[dst] without multiplying: x * 1 is x, so no result differs.     */
   ZKIR_OP_CHECK = 48,
   ZKIR_OP__MAX = 49
 } zkir_opcode;
