@@ -411,6 +411,8 @@ def main():
                 "frac_of_theoretical": achieved / MULHI_PEAK_THEORETICAL,
                 "counted": "128 mul-hi per MUL op and per constraint with two signal factors; the %d constraints "
                            "`value * 1 == signal` are compared without a product and count as checks only" % n_by_one,
+                # the counting of the first round's line (every constraint a product, also those against 1), for comparison only
+                "frac_counting_every_constraint": 128.0 * (h.n_mul_ops + h.n_constraints) * n / (kernel_ms * 1e-3) / mulhi_peak,
                 "kernel_ms": kernel_ms,
                 "fr_mul_per_s_kernel": fr_muls / (kernel_ms * 1e-3),
                 "fr_mul_per_s_register_ceiling": fr_peak,
