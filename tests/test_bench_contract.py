@@ -71,3 +71,18 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert all(e["scaling"] == "strong" and e["value"] > 0 for e in d["also"])
     camp = d["also"][2]
     assert camp["circuits"] == 64 and camp["unsat"] == 0  # both ranks' shares were counted once each
+
+
+def test_products_are_mul_ops_plus_constraints_that_multiply():
+    """bench.py prices a launch at 128 mul-hi per field multiplication: one per MUL op and one per constraint with two
+    signal factors.  A constraint `value * 1 == signal` is compared without a product (the kernels do that, and the
+    count follows); the gadget has none."""
+    import bench
+    import zkir_amd as z
+    t = bench.workload_tape(z)
+    ops, consts = t.ops(), t.consts()
+    by_one = sum(1 for code, _, _, b in ops if code & 0xFF == 48 and b >> 29 == 2 and consts[b & 0x1FFFFFFF] == 1)
+    assert by_one > 100 and bench.checks_by_one(t) == by_one
+    assert bench.products_of(t) == t.hdr.n_mul_ops + t.hdr.n_constraints - by_one
+    g = bench.gadget_tape(z, 5, 4)
+    assert bench.checks_by_one(g) == 0 and bench.products_of(g) == g.hdr.n_mul_ops + g.hdr.n_constraints
