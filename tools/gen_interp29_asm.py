@@ -354,9 +354,7 @@ def build():
     # signal`) multiplies nothing: the left factor goes into the comparison as it is (x * 1 = x mod p, and the
     # comparison is one modulo p).
     a.e("s_cmp_eq_u32 %s, %s" % (OP[3], IN_ONE))
-    a.e("s_cbranch_scc0 .Lz29_b_not_one")
-    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_CHECK))
-    a.e("s_cbranch_scc1 .Lz29_check_one")
+    a.e("s_cbranch_scc1 .Lz29_b_is_one")  # rare: the common path falls through
     a.label(".Lz29_b_not_one")
     # binary ops and CHECK: fetch b, then a (or note that a is the accumulator)
     fetch(a, OP[3], VBB, AD_B, stem="b", tag=TAG_B)
@@ -418,6 +416,9 @@ def build():
     a.label(".Lz29_check_acc")
     mul_stream(a, ACC9, B9, A9)
     a.e("s_branch .Lz29_check_cmp")
+    a.label(".Lz29_b_is_one")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_CHECK))
+    a.e("s_cbranch_scc0 .Lz29_b_not_one")
     a.label(".Lz29_check_one")  # the "product" is the left factor: into the a registers as any operand would be
     fetch(a, OP[2], VA, AD_A, acc_label=".Lz29_one_acc", stem="p", tag=TAG_A)
     wait_loads(a)

@@ -416,9 +416,7 @@ def build():
     # A CHECK whose right factor is the constant 1 (the constraint of a signal with a linear value, `value * 1 ==
     # signal`) multiplies nothing: the left factor is compared as it is.  x * 1 is x bit for bit, so no result changes.
     a.e("s_cmp_eq_u32 %s, %s" % (OP[3], IN_ONE))
-    a.e("s_cbranch_scc0 .Lzk_b_not_one")
-    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_CHECK))
-    a.e("s_cbranch_scc1 .Lzk_check_one")
+    a.e("s_cbranch_scc1 .Lzk_b_is_one")  # rare: the common path falls through
     a.label(".Lzk_b_not_one")
     # binary ops and CHECK: fetch b, then a (or note that a is the accumulator)
     fetch(a, OP[3], VBB, AD_B, stem="b", tag=TAG_B)
@@ -477,6 +475,9 @@ def build():
     a.label(".Lzk_check_acc")
     mul_stream(a, ACC8, B8, W8, after_unpack=lambda: prefetch_next(a, "pd", True))
     a.e("s_branch .Lzk_check_cmp")
+    a.label(".Lzk_b_is_one")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_CHECK))
+    a.e("s_cbranch_scc0 .Lzk_b_not_one")
     a.label(".Lzk_check_one")  # the "product" is the left factor
     fetch(a, OP[2], VA, AD_A, acc_label=".Lzk_one_acc", stem="p", tag=TAG_A)
     wait_loads(a)
