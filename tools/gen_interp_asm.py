@@ -297,8 +297,8 @@ def fetch(a, sop, dst_base, addr, acc_label=None, stem="f", tag=None, vmf=1):
         a.e("s_mov_b32 %s, %s" % (tag, sop))
     a.e("s_lshl_b32 %s, %s, 13" % (T1, T1))
     a.e("v_add_u32 %s, %s, %s" % (addr, T1, IN_VLO))
-    a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen" % (quad(dst_base, 0), addr, D_GS))
-    a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:1024" % (quad(dst_base, 1), addr, D_GS))
+    a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen nt" % (quad(dst_base, 0), addr, D_GS))
+    a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:1024 nt" % (quad(dst_base, 1), addr, D_GS))
     a.e("s_mov_b32 %s, %d" % (VMF, vmf))
     a.e("s_branch %s" % l_done)
     a.label(l_lds)
@@ -591,7 +591,7 @@ def build():
     limb_offsets()
     a.e("s_mov_b64 exec, %s" % IN_LIVE)
     for j in range(8):
-        a.e("buffer_store_dword %s, %s, %s, %s offen" % (E(j), IN_VVEC, D_IO, cst_word(j)))
+        a.e("buffer_store_dword %s, %s, %s, %s offen nt" % (E(j), IN_VVEC, D_IO, cst_word(j)))
     a.e("s_mov_b64 exec, -1")
     a.e("s_branch .Lzk_next")
 
@@ -627,8 +627,8 @@ def build():
     a.e("s_cmp_eq_u32 %s, %d" % (T0, K_GSLOT))
     a.e("s_cbranch_scc0 .Lzk_next")
     a.e("v_add_u32 %s, %s, %s" % (AD_C, T1, IN_VLO))
-    a.e("buffer_store_dwordx4 %s, %s, %s, 0 offen" % (quad(VACC, 0), AD_C, D_GS))
-    a.e("buffer_store_dwordx4 %s, %s, %s, 0 offen offset:1024" % (quad(VACC, 1), AD_C, D_GS))
+    a.e("buffer_store_dwordx4 %s, %s, %s, 0 offen nt" % (quad(VACC, 0), AD_C, D_GS))
+    a.e("buffer_store_dwordx4 %s, %s, %s, 0 offen offset:1024 nt" % (quad(VACC, 1), AD_C, D_GS))
     a.e("s_nop 1")
     a.e("s_branch .Lzk_next")
     a.label(".Lzk_st_lds")
