@@ -297,8 +297,8 @@ def fetch(a, sop, dst_base, addr, acc_label=None, stem="f", tag=None, vmf=1):
         a.e("s_mov_b32 %s, %s" % (tag, sop))
     a.e("s_lshl_b32 %s, %s, 13" % (T1, T1))
     a.e("v_add_u32 %s, %s, %s" % (addr, T1, IN_VLO))
-    a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen nt" % (quad(dst_base, 0), addr, D_GS))
-    a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:1024 nt" % (quad(dst_base, 1), addr, D_GS))
+    a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen" % (quad(dst_base, 0), addr, D_GS))
+    a.e("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:1024" % (quad(dst_base, 1), addr, D_GS))
     a.e("s_mov_b32 %s, %d" % (VMF, vmf))
     a.e("s_branch %s" % l_done)
     a.label(l_lds)
