@@ -627,8 +627,8 @@ def build():
     a.e("s_cmp_eq_u32 %s, %d" % (T0, K_GSLOT))
     a.e("s_cbranch_scc0 .Lzk_next")
     a.e("v_add_u32 %s, %s, %s" % (AD_C, T1, IN_VLO))
-    a.e("buffer_store_dwordx4 %s, %s, %s, 0 offen nt" % (quad(VACC, 0), AD_C, D_GS))
-    a.e("buffer_store_dwordx4 %s, %s, %s, 0 offen offset:1024 nt" % (quad(VACC, 1), AD_C, D_GS))
+    a.e("buffer_store_dwordx4 %s, %s, %s, 0 offen" % (quad(VACC, 0), AD_C, D_GS))
+    a.e("buffer_store_dwordx4 %s, %s, %s, 0 offen offset:1024" % (quad(VACC, 1), AD_C, D_GS))
     a.e("s_nop 1")
     a.e("s_branch .Lzk_next")
     a.label(".Lzk_st_lds")
