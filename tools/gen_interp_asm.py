@@ -590,6 +590,8 @@ def build():
     io_descriptor(IN_OUTB, OP[1])
     limb_offsets()
     a.e("s_mov_b64 exec, %s" % IN_LIVE)
+    # non-temporal: the launch never reads an output back, so its lines need not stay in the L2 beside the slot lines
+    # (the slot stores stay plain: a circuit that runs over few vectors finds its slot lines still in the L2)
     for j in range(8):
         a.e("buffer_store_dword %s, %s, %s, %s offen nt" % (E(j), IN_VVEC, D_IO, cst_word(j)))
     a.e("s_mov_b64 exec, -1")
