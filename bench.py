@@ -31,14 +31,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, datasheet
 MULHI_PEAK_THEORETICAL = 256 * 4 * 16 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock: one v_mul_hi_u32 per lane per clock
 
 
-def workload_tape(z, signal_window=0, linear_terms=1):
+def workload_tape(z, signal_window=0, linear_terms=1, signal_factors=1):
     """configs[1] of BASELINE.json: about 1k rank-1 constraints `out <== lin*lin + lin`, about 1k
     products and about 2k additions/subtractions over 16 inputs.  linear_terms=1 (each `lin` is one
     signal or constant) gives that mix; 2 gives sums of two, i.e. twice the additions and more
-    witness-slot traffic."""
+    witness-slot traffic.  signal_factors=1: both factors of every constraint are signals, so every
+    constraint is quadratic and its check multiplies; 0: a factor is a constant one time in four (the
+    circuit of the earlier rounds' lines: 46 % of its constraints are `value * 1 == signal`)."""
     g = z.default_generator_config()
     g.signal_window = signal_window
     g.max_linear_terms = linear_terms
+    g.signal_factors = signal_factors
     g.min_instructions = g.max_instructions = 4200
     g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = 16, 1, 1, 1
     g.no_loops, g.safe_array_index = 1, 1
@@ -80,12 +83,12 @@ def gadget_tape(z, rounds=20834, strands=0):
 
 
 def synthetic_inputs(torch, n_inputs, n, device, seed):
-    """Uniform 252-bit values (every one below p), limb-major SoA [n_inputs][8][n] of uint32."""
+    """Field elements uniform in [0, p) (254 random bits, redrawn while not below p), limb-major SoA
+    [n_inputs][8][n] of uint32."""
+    from zkir_amd import campaign
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    x = torch.randint(0, 1 << 32, (n_inputs, 8, n), dtype=torch.int64, device=device, generator=gen).to(torch.int32)
-    x[:, 7, :] &= 0x0FFFFFFF
-    return x.contiguous()
+    return campaign.uniform_inputs(torch, n_inputs, n, device, gen)
 
 
 def host_threads():
@@ -163,6 +166,9 @@ def main():
     ap.add_argument("--signal-window", type=int, default=0,
                     help="config2 only: linear terms read the inputs and the last W signals instead of any "
                          "earlier signal (0 = any, the default line)")
+    ap.add_argument("--constant-factors", action="store_true",
+                    help="config2 only: the circuit of the earlier rounds' lines, whose constraint factors are constants "
+                         "one time in four (481 of its 1 047 constraints are `value * 1 == signal`)")
     ap.add_argument("--linear-terms", type=int, default=1, choices=[1, 2],
                     help="config2 only: terms per linear part of a constraint (1: the default line; 2: the "
                          "addition-heavy variant)")
@@ -277,7 +283,8 @@ def main():
     # batch size from 2^13 to 2^21 vectors, by 4x where the plain tape leaves SIMDs without a wavefront
     # and (profiles/r02_d_strands8.txt) eight strands beat four up to 2^14 vectors per GPU (26.9 against 38.2 ms for 4 000 rounds)
     strands = (8 if n <= (1 << 14) else 4) if args.strands == "auto" else int(args.strands)
-    tape = gadget_tape(z, args.gadget_rounds, strands) if gadget else workload_tape(z, args.signal_window, args.linear_terms)
+    tape = gadget_tape(z, args.gadget_rounds, strands) if gadget else \
+        workload_tape(z, args.signal_window, args.linear_terms, 0 if args.constant_factors else 1)
     h = tape.hdr
     want_outputs = not gadget and not args.no_outputs
     m = measure(tape, n, want_outputs, args.steps, args.warmup, 1000 + rank)  # every rank its own vectors
@@ -286,7 +293,7 @@ def main():
     # ---- the fixed-size readings and the campaign sample ("also") -----------------------------------------
     also = []
     if not args.no_extras and not gadget and not args.strong and args.signal_window == 0 and args.linear_terms == 1 \
-            and not args.no_outputs and args.log2_vectors == LOG2_VECTORS:
+            and not args.no_outputs and args.log2_vectors == LOG2_VECTORS and not args.constant_factors:
         mulhi_peak_x = 1.0 if dry else ctx.int_mul_rate(0)
 
         def entry(name, tp, mm, n_rank, steps, scaling):
@@ -298,6 +305,16 @@ def main():
                     "fr_mul_per_s": fr * world / (mm["elapsed"] / steps),
                     "mulhi_frac": 128.0 * fr / (mm["kernel_ms"] * 1e-3) / mulhi_peak_x}
 
+        # the circuit of the earlier rounds' headline lines, so that rounds stay comparable
+        t_old = workload_tape(z, 0, 1, 0)
+        mm = measure(t_old, n, True, args.steps, min(args.warmup, 2), 1500 + rank)
+        assert mm["unsat"] == 0
+        e_old = entry("configuration 2 with the earlier rounds' circuit (seed %d, a factor is a constant one time in four: "
+                      "%d of its %d constraints are `value * 1 == signal` and are compared without a product) x 2^%d vectors "
+                      "per GPU" % (WORKLOAD_SEED, checks_by_one(t_old), t_old.hdr.n_constraints, LOG2_VECTORS),
+                      t_old, mm, n, args.steps, "weak")
+        e_old["n_constraints_times_one"] = checks_by_one(t_old)
+        also.append(e_old)
         if world > 1 and (1 << LOG2_VECTORS) % world == 0:
             n2 = (1 << (10 if dry else LOG2_VECTORS)) // world
             mm = measure(tape, n2, True, args.steps, min(args.warmup, 2), 2000 + rank)
@@ -317,23 +334,30 @@ def main():
             from zkir_amd import campaign
             n_circ, n_vec = (64 if dry else args.campaign_circuits), (16 if dry else 1024)
             ids = campaign.shard(n_circ, rank, world)
-            workers = max(1, min(8, host_threads() // max(1, world if rehearse else 1)))
+            # the ranks of this job share one host (one node): every rank takes its share of the host's threads
+            workers = max(1, min(8, host_threads() // max(1, world)))
             if dry:
                 def evaluator(tapes, n_vectors, circuit_ids):  # no GPU: the lowering and the exchange still run
                     return [0] * len(tapes), 0
             else:
                 evaluator = campaign.GpuEvaluator(local_rank, input_seed=7 + rank)
+            host_stats = {}
             fence()
             t0 = time.perf_counter()
             res_c = campaign.run_local(ids, 7, n_vec, evaluator, group=2048,
-                                       lowered=campaign.lower_parallel(ids, 7, workers=workers))
+                                       lowered=campaign.lower_parallel(ids, 7, workers=workers, stats=host_stats))
+            t_red = time.perf_counter()
             tot = campaign.reduce_results(res_c, dist if world > 1 else None, device if not rehearse else None)
             fence()
-            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            t_end = time.perf_counter()
+            dt = torch.tensor([t_end - t0], dtype=torch.float64, device=device)
             if world > 1:
                 all_reduce(dt, op=dist.ReduceOp.MAX)
             dt = float(dt.item())
+            phases = {"generate_thread_s": host_stats.get("generate_s", 0.0), "lower_thread_s": host_stats.get("lower_s", 0.0),
+                      "generate_lower_wall_s": host_stats.get("host_wall_s", 0.0), "reduce_s": t_end - t_red}
             if not dry:
+                phases.update(evaluator.seconds)
                 evaluator.close()
             also.append({"workload": "configuration 4 (sample): campaign of %d distinct circuits (64 to 4 096 constraints) x %d "
                                      "vectors each, circuit i on GPU i mod N; generate + lower + upload + evaluate + reduce"
@@ -341,7 +365,11 @@ def main():
                          "scaling": "strong", "value": tot["checks"] / dt, "unit": "checks/s", "seconds": dt,
                          "circuits_per_s": tot["circuits"] / dt, "circuits": tot["circuits"], "rejected": tot["rejected"],
                          "unsat": tot["unsat"], "faults": tot["faults"], "n_divergent": tot["n_divergent"],
-                         "host_threads_per_rank": workers})
+                         "host_threads_per_rank": workers,
+                         # rank 0's seconds per phase: generate and lower are thread-seconds over its workers (they run
+                         # beside the evaluation on a helper thread, generate_lower_wall_s being that thread's wall clock);
+                         # upload, inputs (drawing the vectors), evaluate and release are the evaluating thread's wall clock
+                         "phases_rank0": phases})
 
     if rank == 0:
         unsat_total, checks_total = m["unsat"], m["checks"]
@@ -366,7 +394,8 @@ def main():
                 and not gadget and not any(k.startswith("ZKIR_") for k in os.environ)):
             try:
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                    key = "config2_seed%d_2^%d_window4_terms%d" % (WORKLOAD_SEED, LOG2_VECTORS, args.linear_terms)
+                    key = "config2%s_seed%d_2^%d_window4_terms%d" % ("" if args.constant_factors else "_signal_factors",
+                                                                     WORKLOAD_SEED, LOG2_VECTORS, args.linear_terms)
                     traffic = json.load(f)[key]["bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 traffic = None
@@ -390,6 +419,7 @@ def main():
                             ("one generated circuit (extended generator, seed %d%s) x 2^%d uniform input vectors %s; %s" % (
                                 WORKLOAD_SEED,
                                 (", %d-term linear parts" % args.linear_terms) +
+                                (", constant factors one time in four" if args.constant_factors else ", both factors of every constraint signals") +
                                 (", signal window %d" % args.signal_window if args.signal_window else ""),
                                 args.log2_vectors, batch_of,
                                 "witness + outputs + checks" if want_outputs else "witness + checks, outputs not requested")),

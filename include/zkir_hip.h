@@ -48,6 +48,7 @@ extern "C" {
 #define ZKIR_E_LIMIT (-7)     /* size beyond a documented maximum            */
 #define ZKIR_E_INTERNAL (-8)  /* a host-side exception was caught at the ABI */
 #define ZKIR_E_UNSUPPORTED (-9) /* the circuit uses a construct this backend cannot express */
+#define ZKIR_E_BUSY (-10)     /* a shared resource is in use by another context's launch */
 
 /* ------------------------------------------------------------- tape format */
 /*
@@ -219,7 +220,11 @@ typedef struct zkir_generator_config {
   uint32_t max_linear_terms;   /* quadratic_aware: each of the three linear parts of
                                   `lin*lin+lin` has up to this many terms (1 or 2;
                                   0 means 2)                                    */
-  uint32_t reserved[2];
+  uint32_t signal_factors;     /* quadratic_aware, 1: every term of the two factors of
+                                  `lin*lin+lin` is a signal (the draw that would make
+                                  it a constant is not made), so every constraint has
+                                  two signal factors; the addend draws as before   */
+  uint32_t reserved[1];
 } zkir_generator_config;
 
 int32_t zkir_generator_config_default(zkir_generator_config* cfg);
@@ -325,6 +330,11 @@ int32_t zkir_generate_lower_many(const uint64_t* seeds, const zkir_generator_con
                                  const zkir_lower_options* opts, uint32_t threads, zkir_tape** tapes,
                                  int32_t* status_classes);
 
+/* Thread-seconds zkir_generate_lower_many has spent so far, over all its calls and worker threads of this
+ * process, generating circuits and lowering them (a campaign's report of where its host time goes; the
+ * reference has no timing code: src/main.rs:81-92). */
+int32_t zkir_host_phase_seconds(double* generate_s, double* lower_s);
+
 int32_t zkir_tape_header(const zkir_tape* t, zkir_tape_hdr* hdr);
 int32_t zkir_tape_blob(const zkir_tape* t, const void** blob, size_t* bytes);
 /* Where each signal variable sits in an input (which = 0) or output (which = 1)
@@ -383,9 +393,13 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
  * for ZKIR_NOALLOC_SLOT_ROWS witness-slot rows of 9 KiB: a tape with more device slots than
  * that (n_gslots of its header) is refused with ZKIR_E_LIMIT, and a launch gets only as many
  * workgroups as rows / n_gslots, so big tapes run below the rate of zkir_eval_batch_dev.
- * All contexts of one GPU share the array: calls that overlap on one GPU (two contexts, two
- * processes do not count: each has its own copy) race; calls of one context are chained like
- * every other launch of it. */
+ * All contexts of one GPU share the array (two processes do not: each has its own copy): a call that
+ * arrives while ANOTHER context's no-alloc launch is still running on that GPU is refused with ZKIR_E_BUSY
+ * instead of racing with it; calls of one context are chained like every other launch of it.
+ * Under graph capture (the stream is being recorded into a HIP graph) the call records its memsets and its
+ * kernel and nothing else: it neither waits for nor records the context's events, and the busy check is
+ * skipped.  The caller then synchronises with its tape uploads before the capture begins, and keeps replays
+ * of the graph from overlapping any other launch that uses the same context or the same GPU's array. */
 #define ZKIR_NOALLOC_SCRATCH_BYTES (64u << 20)
 #define ZKIR_NOALLOC_SLOT_ROWS (ZKIR_NOALLOC_SCRATCH_BYTES / 9216u - 1u)
 int32_t zkir_eval_batch_dev_noalloc(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa_dev, uint64_t N,
@@ -405,6 +419,13 @@ int32_t zkir_eval_multi(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tap
  *  faults (vectors that divided by zero at run time, over all tapes), reserved}. */
 int32_t zkir_eval_multi_dev(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs_dev,
                             uint64_t N_per_tape, uint64_t* per_tape_unsat_dev, uint64_t* result_dev, void* stream);
+
+/* zkir_eval_multi_dev that also says WHICH tapes faulted: per_tape_faults_dev [n_tapes] uint64 (nullable; with
+ * NULL this is zkir_eval_multi_dev) receives, per tape, the vectors that divided by zero at run time, so a
+ * campaign can name the circuit that faulted and not just the launch.  No counterpart in the reference. */
+int32_t zkir_eval_multi_dev_faults(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs_dev,
+                                   uint64_t N_per_tape, uint64_t* per_tape_unsat_dev, uint64_t* per_tape_faults_dev,
+                                   uint64_t* result_dev, void* stream);
 
 /* Faults (division by zero at run time) seen by the last synchronous call. */
 int32_t zkir_last_faults(const zkir_ctx* ctx, uint64_t* faults);

@@ -77,6 +77,7 @@ class Generator:
         self.name_len = 8  # :264
         self.inputs_readable = self.arithmetic_only = self.quadratic_aware = self.no_loops = 0
         self.forced_inputs = self.safe_array_index = self.signal_window = self.enable_if = self.max_linear_terms = 0
+        self.signal_factors = 0
         for k, v in cfg.items():
             assert hasattr(self, k), k
             setattr(self, k, v)
@@ -298,12 +299,12 @@ class Generator:
         return None if pick is None else ("var", pick[0], pick[1])
 
     # ---- extensions, mirrored from the product so the same seed gives the same circuit ----
-    def gen_linear(self):
+    def gen_linear(self, factor=False):
         sigs = [v["id"] for v in self.scope_vars()
                 if v["role"] in ("input", "output") and v["array_len"] is None and all(v["init"])]
 
         def term():
-            if sigs and self.rng.rand(0, 3) != 0:
+            if sigs and ((factor and self.signal_factors) or self.rng.rand(0, 3) != 0):
                 k = self.rng.rand(0, len(sigs) - 1)
                 keep = self.forced_inputs + self.signal_window
                 if self.signal_window and len(sigs) > keep and self.forced_inputs <= k < len(sigs) - self.signal_window:
@@ -320,7 +321,7 @@ class Generator:
         return ("add" if shape == 1 else "sub", t, term())
 
     def gen_constraint_quadratic(self):
-        a, b, c = self.gen_linear(), self.gen_linear(), self.gen_linear()
+        a, b, c = self.gen_linear(True), self.gen_linear(True), self.gen_linear()
         decl = self.gen_var_decl(("field", None), "output", None)
         self.pending.append(decl)
         self.mark(decl[1], None)

@@ -66,11 +66,13 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert d["dry_run"] is True and d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     cfg = d["config"]
     assert abs(d["value"] - cfg["n_constraints"] * cfg["vectors_per_gpu"] * 2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
-    kinds = [e["workload"].split(":")[0].split(" as ")[0] for e in d["also"]]
-    assert kinds == ["configuration 2", "configuration 5", "configuration 4 (sample)"]
-    assert all(e["scaling"] == "strong" and e["value"] > 0 for e in d["also"])
-    camp = d["also"][2]
+    kinds = [e["workload"].split(":")[0].split(" as ")[0].split(" with ")[0] for e in d["also"]]
+    assert kinds == ["configuration 2", "configuration 2", "configuration 5", "configuration 4 (sample)"]
+    assert [e["scaling"] for e in d["also"]] == ["weak", "strong", "strong", "strong"] and all(e["value"] > 0 for e in d["also"])
+    assert d["config"]["n_constraints_times_one"] == 0 and d["also"][0]["n_constraints_times_one"] > 100
+    camp = d["also"][3]
     assert camp["circuits"] == 64 and camp["unsat"] == 0  # both ranks' shares were counted once each
+    assert camp["host_threads_per_rank"] >= 1 and set(camp["phases_rank0"]) >= {"generate_thread_s", "lower_thread_s", "reduce_s"}
 
 
 def test_products_are_mul_ops_plus_constraints_that_multiply():
@@ -79,7 +81,8 @@ def test_products_are_mul_ops_plus_constraints_that_multiply():
     count follows); the gadget has none."""
     import bench
     import zkir_amd as z
-    t = bench.workload_tape(z)
+    assert bench.checks_by_one(bench.workload_tape(z)) == 0  # the headline circuit: every constraint has two signal factors
+    t = bench.workload_tape(z, signal_factors=0)               # the earlier rounds' circuit
     ops, consts = t.ops(), t.consts()
     by_one = sum(1 for code, _, _, b in ops if code & 0xFF == 48 and b >> 29 == 2 and consts[b & 0x1FFFFFFF] == 1)
     assert by_one > 100 and bench.checks_by_one(t) == by_one

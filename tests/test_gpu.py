@@ -664,25 +664,32 @@ def test_run_time_faults_of_a_multi_tape_launch_reach_the_caller(ctx):
     tapes = [clean, div, clean, rem, div]
     n = 700
     rnd = random.Random(31)
-    blocks, want_faults = [], 0
-    for t in tapes:
+    blocks, want_faults, want_per_tape = [], 0, []
+    for j, t in enumerate(tapes):
         vecs = random_vectors(rnd, t.hdr.n_inputs, n, special_share=0.0)
         if t is not clean:
-            for k in rnd.sample(range(n), 9):
+            for k in rnd.sample(range(n), 7 + j):  # a different count on every faulting tape
                 vecs[k][1] = 0
         inp = z.pack_inputs(vecs, t.hdr.n_inputs)
         _, _, _, f_c = C.eval_cpu(bytes(t.hdr), t.blob(), inp, n, t.hdr.n_outputs, want_outputs=False)
         want_faults += f_c
+        want_per_tape.append(f_c)
         blocks.append(inp.reshape(-1))
-    assert want_faults == 27
+    assert want_per_tape == [0, 8, 0, 10, 11]
     tids = ctx.upload_many(tapes)
     inp = torch.from_numpy(np.concatenate(blocks).view(np.int32)).to(dev)
     unsat = torch.zeros(len(tapes), dtype=torch.int64, device=dev)
+    per_tape = torch.full((len(tapes),), 3, dtype=torch.int64, device=dev)
     res = torch.full((4,), 5, dtype=torch.int64, device=dev)
     ctx.eval_multi_dev(tids, inp.data_ptr(), n, unsat.data_ptr(), torch.cuda.current_stream().cuda_stream, res.data_ptr())
     torch.cuda.synchronize()
     r = res.cpu().numpy().view(np.uint64)
     assert int(r[2]) == want_faults and int(r[0]) == 0 and int(unsat.sum()) == 0
+    # the same launch with a counter per tape: the checker's count on every tape
+    ctx.eval_multi_dev(tids, inp.data_ptr(), n, unsat.data_ptr(), torch.cuda.current_stream().cuda_stream, res.data_ptr(),
+                       per_tape.data_ptr())
+    torch.cuda.synchronize()
+    assert [int(v) for v in per_tape.cpu()] == want_per_tape and int(res.cpu().numpy().view(np.uint64)[2]) == want_faults
     # the host-pointer form reports the same count
     _, faults = ctx.eval_multi(tids, np.concatenate(blocks), n)
     assert faults == want_faults
@@ -693,8 +700,12 @@ def test_run_time_faults_of_a_multi_tape_launch_reach_the_caller(ctx):
     ev = campaign.GpuEvaluator(0, input_seed=3)
     zero_div = hand_tape([(F.OP_INPUT, G(0), I(0), NONE), (F.OP_IDIV, G(1), G(0), K(0)), (F.OP_OUTPUT, 0, G(1), NONE)],
                          [0], 1, 1, 2, 0)
-    got_unsat, got_faults = ev([clean, zero_div], 300, [0, 1])
-    assert got_unsat == [0, 0] and got_faults == 300
+    got_unsat, got_faults = ev([clean, zero_div, clean], 300, [0, 1, 2])
+    assert got_unsat == [0, 0, 0] and got_faults == [0, 300, 0]
+    # run_local flags the circuit that faulted, not the first one of its launch
+    res_c = campaign.run_local([10, 11, 12], 1, 300, lambda tapes, nv, ids: ev([clean, zero_div, clean], nv, ids),
+                               lowered=iter([(10, 0, clean), (11, 0, zero_div), (12, 0, clean)]))
+    assert res_c.divergent == [11] and res_c.faults == 300 and res_c.unsat == 0
     ev.close()
 
 

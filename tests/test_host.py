@@ -88,6 +88,13 @@ def test_generator_matches_restatement_over_seeds():
     for seed in range(1, 8):
         assert z.Generator(seed, ext_config(**cfg)).generate().text() == \
             R.print_text(R.Generator(R.Rng(seed), **cfg).generate())
+    # every factor of a constraint a signal: the constant-or-signal draw of a factor is not made
+    for terms in (1, 2):
+        cfg2 = dict(cfg, signal_factors=1, max_linear_terms=terms)
+        for seed in range(1, 8):
+            text = z.Generator(seed, ext_config(**cfg2)).generate().text()
+            assert text == R.print_text(R.Generator(R.Rng(seed), **cfg2).generate())
+            assert text != z.Generator(seed, ext_config(**dict(cfg2, signal_factors=0))).generate().text()
     # hundreds of written arrays: gen_array_index's one draw per array goes through the generator's jump tables
     cfg = dict(cfg, min_instructions=1500, max_instructions=1500)
     for seed in (3, 4):

@@ -15,7 +15,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZKIR_LIB") or os.path.join(HERE, "libzkir_hip.so")  # ZKIR_LIB: another build of the library (A/B measurements)
 
-OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_LOWER, E_BUFSIZE, E_LIMIT, E_INTERNAL, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
+OK, E_INVALID, E_NOMEM, E_HIP, E_NODEVICE, E_LOWER, E_BUFSIZE, E_LIMIT, E_INTERNAL, E_UNSUPPORTED, E_BUSY = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
 LOWER_CLASSES = {0: "OK", 1: "DoubleAssign", 2: "OOBIndex", 3: "DivByZero", 4: "NonQuadratic", 5: "LoopCap",
                  6: "UnknownControl", 7: "UninitSignal", 8: "BadAst"}
 
@@ -45,7 +45,7 @@ class GeneratorConfig(ctypes.Structure):
     _fields_ = [(n, c_uint32) for n in ("min_instructions", "max_instructions", "statement_budget", "max_array_len",
                                         "max_expr_depth", "loop_init_max", "loop_bound_max", "loop_body_max",
                                         "name_len", "inputs_readable", "arithmetic_only", "quadratic_aware",
-                                        "forced_inputs", "no_loops", "safe_array_index", "signal_window", "enable_if", "max_linear_terms")] + [("reserved", c_uint32 * 2)]
+                                        "forced_inputs", "no_loops", "safe_array_index", "signal_window", "enable_if", "max_linear_terms", "signal_factors")] + [("reserved", c_uint32 * 1)]
 
 
 class LowerOptions(ctypes.Structure):
@@ -82,6 +82,7 @@ def _load():
         "zkir_lower": [c_void_p, P(LowerOptions), P(c_void_p), P(c_int32)],
         "zkir_generate_lower_many": [P(c_uint64), P(GeneratorConfig), c_uint32, P(LowerOptions), c_uint32, P(c_void_p),
                                      P(c_int32)],
+        "zkir_host_phase_seconds": [P(c_double), P(c_double)],
         "zkir_tape_header": [c_void_p, P(TapeHdr)],
         "zkir_tape_blob": [c_void_p, P(c_void_p), P(c_size_t)],
         "zkir_tape_io_map": [c_void_p, c_int32, P(c_uint64), c_size_t, P(c_size_t)],
@@ -96,6 +97,7 @@ def _load():
         "zkir_eval_multi": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, P(c_uint64)],
         "zkir_eval_batch_dev_noalloc": [c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p],
         "zkir_eval_multi_dev": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p],
+        "zkir_eval_multi_dev_faults": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p],
         "zkir_last_faults": [c_void_p, P(c_uint64)],
         "zkir_measure_int_mul_rate": [c_void_p, c_int32, P(c_double)],
         "zkir_measure_fr_mul_rate": [c_void_p, P(c_double)],
@@ -302,6 +304,13 @@ def generate_lower_many(seeds, configs=None, options=None, threads=1):
     return [(classes[k], Tape(c_void_p(tapes[k])) if tapes[k] else None) for k in range(n)]
 
 
+def host_phase_seconds():
+    """(generate, lower): thread-seconds generate_lower_many has spent in each so far, in this process."""
+    g, l = c_double(), c_double()
+    _host_check(lib.zkir_host_phase_seconds(byref(g), byref(l)))
+    return g.value, l.value
+
+
 def pack_inputs(vectors, n_inputs):
     """list of per-vector lists of ints -> limb-major SoA uint32 [n_inputs][8][N]."""
     n = len(vectors)
@@ -405,10 +414,15 @@ class Context:
         """eval_batch_dev on the library's fixed scratch array: the call allocates nothing."""
         self._check(lib.zkir_eval_batch_dev_noalloc(self._h, tid, inputs_ptr, n, outputs_ptr, result_ptr, stream))
 
-    def eval_multi_dev(self, tids, inputs_ptr, n_per_tape, unsat_ptr, stream=None, result_ptr=None):
-        """result_ptr: None, or 4 uint64 of device memory for {0, first unsat pair, faults, reserved}."""
+    def eval_multi_dev(self, tids, inputs_ptr, n_per_tape, unsat_ptr, stream=None, result_ptr=None, faults_ptr=None):
+        """result_ptr: None, or 4 uint64 of device memory for {0, first unsat pair, faults, reserved}.
+        faults_ptr: None, or one uint64 per tape of device memory for the vectors of that tape that faulted."""
         ids = (c_uint32 * len(tids))(*tids)
-        self._check(lib.zkir_eval_multi_dev(self._h, ids, len(tids), inputs_ptr, n_per_tape, unsat_ptr, result_ptr, stream))
+        if faults_ptr is None:
+            self._check(lib.zkir_eval_multi_dev(self._h, ids, len(tids), inputs_ptr, n_per_tape, unsat_ptr, result_ptr, stream))
+        else:
+            self._check(lib.zkir_eval_multi_dev_faults(self._h, ids, len(tids), inputs_ptr, n_per_tape, unsat_ptr, faults_ptr,
+                                                       result_ptr, stream))
 
     def int_mul_rate(self, which):
         d = c_double()

@@ -39,15 +39,18 @@ def campaign_config(circuit_id, min_constraints=64, max_constraints=4096):
     return g
 
 
-def lower_parallel(circuit_ids, base_seed, workers=8, window=64, lower_options=None, config_of=campaign_config):
+def lower_parallel(circuit_ids, base_seed, workers=8, window=64, lower_options=None, config_of=campaign_config, stats=None):
     """Generate and lower campaign circuits on `workers` host threads; yields
     (circuit id, class, Tape or None) in id order.  The circuits go to the library `window` x workers
     at a time (zkir_generate_lower_many: the threads are the library's own and nothing passes through
     Python per circuit); one helper thread keeps the next batch in the making while the consumer works
     on the last one (ctypes drops the interpreter lock for the call, and nothing is forked from a process
-    that may already hold a GPU context)."""
+    that may already hold a GPU context).  stats: optional dict; "host_wall_s" receives the seconds the helper
+    thread spent inside the library, "generate_s" / "lower_s" the thread-seconds of the two phases over all workers.
+    Closing the generator early (the consumer gave up) stops the helper thread at its next batch."""
     import queue
     import threading
+    import time
     if lower_options is None:
         # a campaign is bound by the host side (generate + lower cost a few ms per circuit, its evaluation some tens of
         # microseconds), so lower skips the search for the statement order with the least device-memory traffic
@@ -56,28 +59,52 @@ def lower_parallel(circuit_ids, base_seed, workers=8, window=64, lower_options=N
     ids = list(circuit_ids)
     step = max(1, window * workers)
     batches = queue.Queue(maxsize=2)
+    stop = threading.Event()
+    g0, l0 = api.host_phase_seconds()
+
+    def hand_over(item):
+        """put that gives up when the consumer has gone (a bare put would block for ever and keep the tapes alive)"""
+        while not stop.is_set():
+            try:
+                batches.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def produce():
         try:
             for at in range(0, len(ids), step):
+                if stop.is_set():
+                    return
                 part = ids[at:at + step]
+                t0 = time.perf_counter()
                 made = api.generate_lower_many([circuit_seed(base_seed, c) for c in part], [config_of(c) for c in part],
                                                lower_options, workers)
-                batches.put((part, made))
-            batches.put(None)
+                if stats is not None:
+                    stats["host_wall_s"] = stats.get("host_wall_s", 0.0) + time.perf_counter() - t0
+                if not hand_over((part, made)):
+                    return
+            hand_over(None)
         except BaseException as e:  # hand the failure to the consumer instead of leaving it waiting
-            batches.put(e)
+            hand_over(e)
 
     threading.Thread(target=produce, daemon=True).start()
-    while True:
-        item = batches.get()
-        if item is None:
-            return
-        if isinstance(item, BaseException):
-            raise item
-        part, made = item
-        for cid, (cls, tape) in zip(part, made):
-            yield cid, cls, tape
+    try:
+        while True:
+            item = batches.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            part, made = item
+            for cid, (cls, tape) in zip(part, made):
+                yield cid, cls, tape
+    finally:
+        stop.set()
+        if stats is not None:  # (process-wide counters: two campaigns lowering at once would see each other's time)
+            g1, l1 = api.host_phase_seconds()
+            stats["generate_s"], stats["lower_s"] = g1 - g0, l1 - l0
 
 
 class LocalResult:
@@ -103,7 +130,8 @@ def run_local(circuit_ids, base_seed, n_vectors, evaluate, config_of=campaign_co
 
     evaluate(tapes, n_vectors, circuit_ids) -> (per-tape unsat list, faults) runs a group of
     lowered tapes for n_vectors fresh random vectors each; on a GPU rank it is
-    GpuEvaluator below.  expected_class maps circuit id -> class name when an external
+    GpuEvaluator below.  `faults` is the per-tape list of vectors that divided by zero (or, from an
+    evaluator that only knows the launch's total, an integer: the group's first circuit is then flagged).  expected_class maps circuit id -> class name when an external
     verdict (e.g. circom's) is known; a different class makes the circuit divergent.
     """
     res = LocalResult()
@@ -115,14 +143,15 @@ def run_local(circuit_ids, base_seed, n_vectors, evaluate, config_of=campaign_co
         ids = [i for i, _ in pending]
         tapes = [t for _, t in pending]
         unsat, faults = evaluate(tapes, n_vectors, ids)
-        res.faults += faults
-        for cid, tape, u in zip(ids, tapes, unsat):
+        per_tape = list(faults) if not isinstance(faults, int) else None
+        res.faults += sum(per_tape) if per_tape is not None else faults
+        for k, (cid, tape, u) in enumerate(zip(ids, tapes, unsat)):
             res.checks += tape.hdr.n_constraints * n_vectors
             res.unsat += u
-            if u:
+            if u or (per_tape is not None and per_tape[k]):  # the circuit that failed a check or faulted
                 res.divergent.append(cid)
-        if faults and not any(unsat):
-            res.divergent.extend(ids[:1])  # a fault is reported per launch: flag the group's first circuit
+        if per_tape is None and faults and not any(unsat):
+            res.divergent.extend(ids[:1])  # only a total is known: flag the group's first circuit
         pending.clear()
 
     def lower_here():
@@ -149,6 +178,32 @@ def run_local(circuit_ids, base_seed, n_vectors, evaluate, config_of=campaign_co
     return res
 
 
+P_LIMBS = (0xf0000001, 0x43e1f593, 0x79b97091, 0x2833e848, 0x8181585d, 0xb85045b6, 0xe131a029, 0x30644e72)
+
+
+def uniform_inputs(torch, n_elements, n_vectors, device, generator):
+    """[n_elements][8][n_vectors] int32: field elements uniform in [0, p), limb-major.  Rejection sampling on the
+    device: 254 random bits per candidate (p has 254 bits), kept when below p (three candidates in four are)."""
+    need = n_elements * n_vectors
+    if need == 0:
+        return torch.zeros((max(n_elements, 1), 8, max(n_vectors, 1)), dtype=torch.int32, device=device)[:n_elements]
+    kept, have = [], 0
+    while have < need:
+        m = int((need - have) * 1.36) + 4096
+        x = torch.randint(0, 1 << 32, (8, m), dtype=torch.int64, device=device, generator=generator)
+        x[7] &= 0x3FFFFFFF
+        below = torch.zeros(m, dtype=torch.bool, device=device)
+        equal = torch.ones(m, dtype=torch.bool, device=device)
+        for limb in range(7, -1, -1):
+            below |= equal & (x[limb] < P_LIMBS[limb])
+            equal &= x[limb] == P_LIMBS[limb]
+        good = x[:, below][:, :need - have].to(torch.int32)
+        kept.append(good)
+        have += good.shape[1]
+    flat = kept[0] if len(kept) == 1 else torch.cat(kept, dim=1)
+    return flat.view(8, n_elements, n_vectors).permute(1, 0, 2).contiguous()
+
+
 class GpuEvaluator:
     """evaluate() for run_local on one MI355X: inputs are drawn on the device, every
     group of tapes is one launch (one tape per workgroup pass)."""
@@ -160,25 +215,33 @@ class GpuEvaluator:
         self.ctx = api.Context(device_index)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(input_seed)
+        self.seconds = {"upload_s": 0.0, "inputs_s": 0.0, "evaluate_s": 0.0, "release_s": 0.0}  # host wall clock per phase
 
     def __call__(self, tapes, n_vectors, circuit_ids):
+        import time
         torch = self.torch
+        t0 = time.perf_counter()
         tids = self.ctx.upload_many(tapes)
-        words = sum(t.hdr.n_inputs for t in tapes) * 8 * n_vectors
-        inp = torch.randint(0, 1 << 32, (max(words, 1),), dtype=torch.int64, device=self.device,
-                            generator=self.gen).to(torch.int32)
-        # keep every element below p: clear the top 4 bits of limb 7 of each element (the tapes' blocks
-        # [n_inputs][8][n_vectors] lie one after the other, so the whole buffer is [elements][8][n_vectors])
-        if words:
-            inp[:words].view(-1, 8, n_vectors)[:, 7, :] &= 0x0FFFFFFF
+        t1 = time.perf_counter()
+        # the tapes' blocks [n_inputs][8][n_vectors] lie one after the other: the whole buffer is [elements][8][n_vectors]
+        inp = uniform_inputs(torch, max(1, sum(t.hdr.n_inputs for t in tapes)), n_vectors, self.device, self.gen)
         unsat = torch.zeros(len(tapes), dtype=torch.int64, device=self.device)
+        faults = torch.zeros(len(tapes), dtype=torch.int64, device=self.device)
         result = torch.zeros(4, dtype=torch.int64, device=self.device)  # {0, first unsat pair, faults, reserved}
         stream = torch.cuda.current_stream().cuda_stream
-        self.ctx.eval_multi_dev(tids, inp.data_ptr(), n_vectors, unsat.data_ptr(), stream, result.data_ptr())
         torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        self.ctx.eval_multi_dev(tids, inp.data_ptr(), n_vectors, unsat.data_ptr(), stream, result.data_ptr(), faults.data_ptr())
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
         for tid in tids:
             self.ctx.release(tid)
-        return [int(v) for v in unsat.cpu()], int(result[2].item())
+        out = [int(v) for v in unsat.cpu()], [int(v) for v in faults.cpu()]
+        assert sum(out[1]) == int(result[2].item())
+        t4 = time.perf_counter()
+        for k, dt in (("upload_s", t1 - t0), ("inputs_s", t2 - t1), ("evaluate_s", t3 - t2), ("release_s", t4 - t3)):
+            self.seconds[k] += dt
+        return out
 
     def close(self):
         self.ctx.close()

@@ -208,7 +208,7 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
                    const uint32_t* __restrict__ inputs, uint32_t* __restrict__ outputs,
                    uint4* __restrict__ gslot_pool, uint32_t gslots_per_block,
                    uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats,
-                   uint32_t* __restrict__ work_counter) {
+                   uint32_t* __restrict__ work_counter, uint64_t* __restrict__ faults_per_tape) {
   __shared__ uint32_t next_item;
   LaneCtx cx;
   cx.gslots = gslot_pool + (size_t)blockIdx.x * gslots_per_block * 2 * kBlock;
@@ -336,7 +336,10 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
     const uint64_t wave_faults = __popcll(__ballot(live && fault != 0));
     if ((threadIdx.x & 63) == 0) {
       if (wave_unsat) atomicAdd((unsigned long long*)&unsat_per_tape[td.unsat_index], (unsigned long long)wave_unsat);
-      if (wave_faults) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)wave_faults);
+      if (wave_faults) {
+        atomicAdd((unsigned long long*)&stats[1], (unsigned long long)wave_faults);
+        if (faults_per_tape) atomicAdd((unsigned long long*)&faults_per_tape[td.unsat_index], (unsigned long long)wave_faults);
+      }
     }
     if (first_bad != 0xffffffffu)
       atomicMin((unsigned long long*)&stats[0], (unsigned long long)((vec << 32) | first_bad));
@@ -667,7 +670,7 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
                          uint32_t* work_counter, uint32_t grid, uint32_t strands, uint32_t xslots, uint32_t n_cu,
-                         hipStream_t stream) {
+                         uint64_t* faults_per_tape, hipStream_t stream) {
   if (n_cu == 0 || n_cu > 0xffffu) return hipErrorInvalidValue;
   const size_t lds_bytes = interp_lds_bytes(variant, lslots, strands, xslots);
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
@@ -688,8 +691,13 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
   // each) instead of running in the order they were placed, the last one finishing alone.
   static const uint32_t turn_shift = std::getenv("ZKIR_TURN_SHIFT") ? (uint32_t)std::atoi(std::getenv("ZKIR_TURN_SHIFT")) : 14u;  // measurement aid; 99: no turns
   uint32_t turns = strands && grid > n_cu && turn_shift < 32 ? (n_cu | turn_shift << 16) : 0u;
-  void* args[] = {&tapes_dev, &n_tapes, &passes_per_tape, &n_vectors, &inputs, &outputs, &pool, &gslots_per_block,
-                  &unsat_per_tape, &stats, &work_counter, &victim_row, &strands, &lslots, &turns};
+  // the compiled kernels take the per-tape fault counters as their last argument (only they can fault: the
+  // generated streams run + - * tapes); the generated-stream kernels take the four that follow
+  void* args_compiled[] = {&tapes_dev, &n_tapes, &passes_per_tape, &n_vectors, &inputs, &outputs, &pool, &gslots_per_block,
+                           &unsat_per_tape, &stats, &work_counter, &faults_per_tape};
+  void* args_stream[] = {&tapes_dev, &n_tapes, &passes_per_tape, &n_vectors, &inputs, &outputs, &pool, &gslots_per_block,
+                         &unsat_per_tape, &stats, &work_counter, &victim_row, &strands, &lslots, &turns};
+  void** args = (variant == 2 || variant == 3) ? args_stream : args_compiled;
   return hipLaunchKernel(interp_entry(variant), dim3(grid), dim3(strands == 8 ? 2 * kBlock : kBlock), args, lds_bytes, stream);
 }
 

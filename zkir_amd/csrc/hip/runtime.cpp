@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -22,7 +23,7 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
                          uint64_t n_vectors, const uint32_t* inputs, uint32_t* outputs, void* gslot_pool,
                          uint32_t gslots_per_block, uint32_t lslots, uint64_t* unsat_per_tape, uint64_t* stats,
                          uint32_t* work_counter, uint32_t grid, uint32_t strands, uint32_t xslots, uint32_t n_cu,
-                         hipStream_t stream);
+                         uint64_t* faults_per_tape, hipStream_t stream);
 hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots, int* blocks);
 size_t interp_lds_need(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots);
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream);
@@ -58,6 +59,7 @@ struct TapeSlab {
 struct zkir_ctx {
   int device = 0;
   int n_cu = 0;
+  size_t lds_per_cu = 0;  // bytes of LDS a workgroup may take on this device
   std::string err;
   std::map<zkir_tape_id, DevTape> tapes;
   zkir_tape_id next_id = 1;
@@ -297,11 +299,16 @@ int32_t plan_group(zkir_ctx* ctx, const Group& G, int kind, uint64_t N, size_t p
     if (P->variant != 2 && P->variant != 3)
       return fail(ctx, ZKIR_E_LIMIT, "strand tapes take fewer than 466 033 device slots per strand");
   }
-  const size_t lds = zkir::interp_lds_need(P->variant, G.max_lslots, P->strands, G.max_xslots);
-  if (lds > 160 * 1024)
+  size_t lds = zkir::interp_lds_need(P->variant, G.max_lslots, P->strands, G.max_xslots);
+  // the 29-bit stream's rows are 9 KiB and it keeps a table: a launch that does not fit with them may fit the 32-bit stream's 8 KiB rows
+  if (lds > ctx->lds_per_cu && P->variant == 3 && zkir::interp_lds_need(2, G.max_lslots, P->strands, G.max_xslots) <= ctx->lds_per_cu) {
+    P->variant = 2;
+    lds = zkir::interp_lds_need(2, G.max_lslots, P->strands, G.max_xslots);
+  }
+  if (lds > ctx->lds_per_cu)
     return fail(ctx, ZKIR_E_LIMIT, "the tapes of this launch need " + std::to_string(lds) + " bytes of LDS per workgroup (" +
                                        std::to_string(G.max_lslots) + " window rows, " + std::to_string(G.max_xslots) +
-                                       " exchange slots); a CU has 163840");
+                                       " exchange slots); a CU has " + std::to_string(ctx->lds_per_cu));
   P->grid = pick_grid(ctx, work, P->variant, G.max_lslots, P->strands, G.max_xslots);
   if (pool_rows_cap && G.max_gslots) {
     const uint64_t rows = (uint64_t)G.max_gslots * row_sets_of_kind(kind);
@@ -313,18 +320,29 @@ int32_t plan_group(zkir_ctx* ctx, const Group& G, int kind, uint64_t N, size_t p
   return ZKIR_OK;
 }
 
+// is the caller recording `stream` into a HIP graph?  Events recorded outside the capture may not be waited for
+// inside it, and an event recorded inside it means nothing to launches outside
+bool stream_is_capturing(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
 // what every launch of a context does first on its stream: wait for the constants of fresh uploads and for
-// the launch before it (which may be on another stream and shares the counters, descriptors and slots)
+// the launch before it (which may be on another stream and shares the counters, descriptors and slots).
+// While the stream is being captured into a graph neither is done: the caller has synchronised with its uploads
+// before the capture began and orders the graph's replays against the context's other launches itself.
 int32_t chain_stream(zkir_ctx* ctx, hipStream_t stream) {
+  if (stream_is_capturing(stream)) return ZKIR_OK;
+  // the constants of an upload are converted on the null stream: a launch on any other stream has to wait for them
+  if (ctx->upload_pending) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->upload_done, 0));
   static const bool off = std::getenv("ZKIR_NO_CHAIN") != nullptr;  // measurement aid: the caller keeps to one stream
   if (off) return ZKIR_OK;
-  if (ctx->upload_pending) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->upload_done, 0));
   if (ctx->launch_recorded) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->launch_done, 0));
   return ZKIR_OK;
 }
 int32_t chain_done(zkir_ctx* ctx, hipStream_t stream) {
   static const bool off = std::getenv("ZKIR_NO_CHAIN") != nullptr;
-  if (off) {
+  if (off || stream_is_capturing(stream)) {
     ctx->launched_since_sync = true;
     return ZKIR_OK;
   }
@@ -342,9 +360,10 @@ void note_device_idle(zkir_ctx* ctx) {
 
 int32_t launch_group(zkir_ctx* ctx, const Group& G, const Plan& P, const TapeDesc* descs_dev, const uint32_t* in_dev, uint64_t N,
                      uint32_t* out_dev, void* pool, uint32_t* counter, uint64_t* unsat_dev, uint64_t* stats_dev,
-                     hipStream_t stream) {
+                     uint64_t* faults_per_tape_dev, hipStream_t stream) {
   hipError_t e = zkir::launch_interp(P.variant, descs_dev, G.count, P.passes, N, in_dev, out_dev, pool, G.max_gslots,
-                                     G.max_lslots, unsat_dev, stats_dev, counter, P.grid, P.strands, G.max_xslots, (uint32_t)ctx->n_cu, stream);
+                                     G.max_lslots, unsat_dev, stats_dev, counter, P.grid, P.strands, G.max_xslots, (uint32_t)ctx->n_cu,
+                                     faults_per_tape_dev, stream);
   if (e != hipSuccess) return hip_fail(ctx, e, "launch zkir_interp_kernel");
   return ZKIR_OK;
 }
@@ -380,7 +399,7 @@ int32_t run_one(zkir_ctx* ctx, const DevTape& t, const uint32_t* in_dev, uint64_
   rc = chain_stream(ctx, stream);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemsetAsync(counter, 0, 256, stream));
-  rc = launch_group(ctx, G, P, (const TapeDesc*)t.desc, in_dev, N, out_dev, pool, counter, unsat_dev, stats_dev, stream);
+  rc = launch_group(ctx, G, P, (const TapeDesc*)t.desc, in_dev, N, out_dev, pool, counter, unsat_dev, stats_dev, nullptr, stream);
   if (rc) return rc;
   return chain_done(ctx, stream);
 }
@@ -411,7 +430,7 @@ int32_t desc_stage_acquire(zkir_ctx* ctx, size_t bytes, int* which) {
 // entries ({packed first unsat, faults}); both must already be initialised.  Input / output offsets and
 // the unsat index of a tape are those of its place in the call.
 int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint32_t* in_dev, uint64_t N,
-                  uint32_t* out_dev, uint64_t* unsat_dev, uint64_t* stats_dev, hipStream_t stream) {
+                  uint32_t* out_dev, uint64_t* unsat_dev, uint64_t* stats_dev, uint64_t* faults_per_tape_dev, hipStream_t stream) {
   if (N == 0 || n == 0) return ZKIR_OK;
   if (N >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "N must be below 2^32");
   Group G[kKinds];
@@ -460,7 +479,7 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
   for (int k = 0; k < kKinds; k++) {
     if (!G[k].count) continue;
     rc = launch_group(ctx, G[k], plan[k], (const TapeDesc*)ctx->desc_buf + desc_at, in_dev, N, out_dev, ctx->gslot_pool,
-                      (uint32_t*)ctx->work_counter + 16 * k, unsat_dev, stats_dev, stream);
+                      (uint32_t*)ctx->work_counter + 16 * k, unsat_dev, stats_dev, faults_per_tape_dev, stream);
     if (rc) return rc;
     ctx->launched_since_sync = true;
     desc_at += G[k].count;
@@ -470,10 +489,24 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
 
 }  // namespace
 
-// Scratch of zkir_eval_batch_dev_noalloc: the work counter (first 8 KiB) and witness-slot rows of 8 KiB.
+// Scratch of zkir_eval_batch_dev_noalloc: the work counter (in the first 9 KiB) and witness-slot rows of 9 KiB.
 // Every GPU the library runs on holds its own copy until the process ends.  In host code the array's name
 // is only a handle for hipGetSymbolAddress; the address kernels and memsets use is zkir_ctx::static_scratch.
 static __device__ __align__(256) unsigned char scratch[ZKIR_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+// Who launched on a device's scratch array last, and the event behind that launch: a call of ANOTHER context that
+// arrives while that launch is still running would share its rows and its counter, so it is refused (ZKIR_E_BUSY)
+// instead of racing.  Calls of one context are chained by its own events.  Under graph capture nothing is recorded.
+constexpr int kMaxDevices = 64;
+struct ScratchOwner {
+  const zkir_ctx* ctx = nullptr;
+  hipEvent_t done = nullptr;
+  bool recorded = false;
+};
+std::mutex g_scratch_lock;
+ScratchOwner g_scratch_owner[kMaxDevices];
+}  // namespace
 
 extern "C" {
 
@@ -490,6 +523,7 @@ int32_t zkir_ctx_create(int32_t device, zkir_ctx** out) {
   if (!ctx) return ZKIR_E_NOMEM;
   ctx->device = device;
   ctx->n_cu = prop.multiProcessorCount;
+  ctx->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? (size_t)prop.maxSharedMemoryPerMultiProcessor : (size_t)160 * 1024;
   // with `device` current: the address of this device's copy of the scratch array
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->result_buf, 4 * sizeof(uint64_t)) != hipSuccess ||
       hipMalloc(&ctx->work_counter, 256) != hipSuccess ||
@@ -502,6 +536,10 @@ int32_t zkir_ctx_create(int32_t device, zkir_ctx** out) {
     if (ctx->launch_done) (void)hipEventDestroy(ctx->launch_done);
     delete ctx;
     return ZKIR_E_HIP;
+  }
+  if (device < kMaxDevices) {  // the no-alloc entry point's per-device event is made here: that call creates nothing
+    std::lock_guard<std::mutex> g(g_scratch_lock);
+    if (!g_scratch_owner[device].done) (void)hipEventCreateWithFlags(&g_scratch_owner[device].done, hipEventDisableTiming);
   }
   *out = ctx;
   return ZKIR_OK;
@@ -665,10 +703,25 @@ int32_t zkir_eval_batch_dev_noalloc(zkir_ctx* ctx, zkir_tape_id tape, const uint
   if (it->second.hdr.n_inputs && N && !inputs_soa_dev) return fail(ctx, ZKIR_E_INVALID, "inputs required");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
+  const bool capturing = stream_is_capturing(s);
+  ScratchOwner* owner = ctx->device < kMaxDevices ? &g_scratch_owner[ctx->device] : nullptr;
+  std::unique_lock<std::mutex> guard(g_scratch_lock, std::defer_lock);
+  if (owner && !capturing) {
+    guard.lock();
+    if (owner->recorded && owner->ctx != ctx && hipEventQuery(owner->done) == hipErrorNotReady)
+      return fail(ctx, ZKIR_E_BUSY, "another context's zkir_eval_batch_dev_noalloc launch is still running on this GPU's scratch array");
+  }
   HIP_TRY(ctx, init_result(result_dev, s));
   // the counter is cleared by run_one; slot rows need no clearing (a tape writes a slot before it reads it)
-  return run_one(ctx, it->second, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s, ctx->static_scratch,
-                 (size_t)ZKIR_NOALLOC_SCRATCH_BYTES);
+  const int32_t rc = run_one(ctx, it->second, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s, ctx->static_scratch,
+                             (size_t)ZKIR_NOALLOC_SCRATCH_BYTES);
+  if (rc == ZKIR_OK && owner && !capturing && owner->done) {
+    if (hipEventRecord(owner->done, s) == hipSuccess) {
+      owner->ctx = ctx;
+      owner->recorded = true;
+    }
+  }
+  return rc;
 }
 
 namespace {
@@ -765,6 +818,12 @@ int32_t zkir_eval_batch(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs
 
 int32_t zkir_eval_multi_dev(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs_dev,
                             uint64_t N_per_tape, uint64_t* per_tape_unsat_dev, uint64_t* result_dev, void* stream) {
+  return zkir_eval_multi_dev_faults(ctx, tapes, n_tapes, inputs_dev, N_per_tape, per_tape_unsat_dev, nullptr, result_dev, stream);
+}
+
+int32_t zkir_eval_multi_dev_faults(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs_dev,
+                                   uint64_t N_per_tape, uint64_t* per_tape_unsat_dev, uint64_t* per_tape_faults_dev,
+                                   uint64_t* result_dev, void* stream) {
   if (!ctx || (!tapes && n_tapes) || (!per_tape_unsat_dev && n_tapes)) return ZKIR_E_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
@@ -773,7 +832,8 @@ int32_t zkir_eval_multi_dev(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n
   HIP_TRY(ctx, init_result(res, s));
   if (n_tapes == 0) return ZKIR_OK;
   HIP_TRY(ctx, hipMemsetAsync(per_tape_unsat_dev, 0, (size_t)n_tapes * sizeof(uint64_t), s));
-  return run_tapes(ctx, tapes, n_tapes, inputs_dev, N_per_tape, nullptr, per_tape_unsat_dev, res + 1, s);
+  if (per_tape_faults_dev) HIP_TRY(ctx, hipMemsetAsync(per_tape_faults_dev, 0, (size_t)n_tapes * sizeof(uint64_t), s));
+  return run_tapes(ctx, tapes, n_tapes, inputs_dev, N_per_tape, nullptr, per_tape_unsat_dev, res + 1, per_tape_faults_dev, s);
 }
 
 int32_t zkir_eval_multi(zkir_ctx* ctx, const zkir_tape_id* tapes, uint32_t n_tapes, const uint32_t* inputs,

@@ -2,6 +2,7 @@
 // transpile) and lower, behind a C boundary that never lets an exception through.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -23,6 +24,12 @@
 namespace {
 
 thread_local std::string g_host_error;
+
+// thread-nanoseconds zkir_generate_lower_many has spent generating and lowering, over all its calls and threads
+std::atomic<uint64_t> g_generate_ns{0}, g_lower_ns{0};
+inline uint64_t now_ns() {
+  return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 int32_t copy_out(const std::string& s, char* buf, size_t cap, size_t* needed) {
   if (needed) *needed = s.size() + 1;
@@ -216,16 +223,28 @@ int32_t zkir_generate_lower_many(const uint64_t* seeds, const zkir_generator_con
   std::mutex error_lock;
   std::string first_error;
   auto work = [&]() {
+    uint64_t gen_ns = 0, low_ns = 0;
+    struct Tally {  // added to the process-wide counters when the worker ends, however it ends
+      uint64_t &g, &l;
+      ~Tally() {
+        g_generate_ns.fetch_add(g);
+        g_lower_ns.fetch_add(l);
+      }
+    } tally{gen_ns, low_ns};
     for (;;) {
       const uint32_t k = next.fetch_add(1);
       if (k >= n || failed.load() != ZKIR_OK) return;
       zkir_circuit* c = nullptr;
+      const uint64_t t0 = now_ns();
       int32_t rc = zkir_generate(seeds[k], cfgs ? &cfgs[k] : nullptr, &c);
+      const uint64_t t1 = now_ns();
+      gen_ns += t1 - t0;
       if (rc == ZKIR_OK) {
         rc = zkir_lower(c, &o, &tapes[k], &status_classes[k]);
         if (rc == ZKIR_E_LOWER) rc = ZKIR_OK;  // a refused circuit is a result, not a failure of the call
       }
       zkir_circuit_free(c);
+      low_ns += now_ns() - t1;
       if (rc != ZKIR_OK) {
         std::lock_guard<std::mutex> g(error_lock);
         if (failed.load() == ZKIR_OK) {
@@ -236,16 +255,29 @@ int32_t zkir_generate_lower_many(const uint64_t* seeds, const zkir_generator_con
       }
     }
   };
+  // The pool lives outside the try block: when a thread cannot be started (std::system_error at the thread limit)
+  // the ones that did start are joined, not destroyed while joinable (that would end the process), and the
+  // circuits are made by the threads there are.
+  std::vector<std::thread> pool;
   try {
     const uint32_t n_threads = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(threads ? threads : 1, n), 256));
-    std::vector<std::thread> pool;
-    for (uint32_t t = 1; t < n_threads; t++) pool.emplace_back(work);
+    pool.reserve(n_threads);
+    try {
+      for (uint32_t t = 1; t < n_threads; t++) pool.emplace_back(work);
+    } catch (const std::system_error&) {
+    }
     work();
-    for (std::thread& t : pool) t.join();
   } catch (const std::exception& e) {
+    std::lock_guard<std::mutex> g(error_lock);
     failed.store(ZKIR_E_INTERNAL);
     first_error = e.what();
+  } catch (...) {
+    std::lock_guard<std::mutex> g(error_lock);
+    failed.store(ZKIR_E_INTERNAL);
+    first_error = "unknown exception";
   }
+  for (std::thread& t : pool)
+    if (t.joinable()) t.join();
   if (failed.load() != ZKIR_OK) {
     for (uint32_t k = 0; k < n; k++) {
       zkir_tape_free(tapes[k]);
@@ -254,6 +286,13 @@ int32_t zkir_generate_lower_many(const uint64_t* seeds, const zkir_generator_con
     g_host_error = first_error;
   }
   return failed.load();
+}
+
+int32_t zkir_host_phase_seconds(double* generate_s, double* lower_s) {
+  if (!generate_s || !lower_s) return ZKIR_E_INVALID;
+  *generate_s = 1e-9 * (double)g_generate_ns.load();
+  *lower_s = 1e-9 * (double)g_lower_ns.load();
+  return ZKIR_OK;
 }
 
 int32_t zkir_tape_header(const zkir_tape* t, zkir_tape_hdr* hdr) {

@@ -439,10 +439,11 @@ std::optional<Expr> Generator::gen_array_index(size_t) {
 // ---- extensions (no counterpart in the reference) ----
 
 // a*x + b style term over readable signals and constants: degree <= 1 in the signals
-Expr Generator::gen_linear() {
+Expr Generator::gen_linear(bool factor) {
   const OrderedSet& sigs = scope_stack_.ready_signals;
+  const bool always_signal = factor && cfg_.signal_factors;  // extension: a factor never draws a constant
   auto term = [&]() -> Expr {
-    if (sigs.count() && rng_.rand(0, 3) != 0) {
+    if (sigs.count() && (always_signal || rng_.rand(0, 3) != 0)) {
       size_t k = rng_.rand(0, sigs.count() - 1);
       // extension: with a signal window, a draw that falls on an older signal is folded onto
       // the forced inputs and the most recent `signal_window` signals
@@ -462,7 +463,7 @@ Expr Generator::gen_linear() {
 
 // `fresh output <== lin * lin + lin`: a real rank-1 constraint
 std::optional<Instruction> Generator::gen_constraint_quadratic() {
-  Expr a = gen_linear(), b = gen_linear(), c = gen_linear();
+  Expr a = gen_linear(true), b = gen_linear(true), c = gen_linear(false);
   auto decl = gen_var_decl(VariableType::Field(), VariableRole::Signal(SignalType::Output), std::nullopt);
   const VarRef out = decl->var.var_ref;
   pending_.push_back(std::move(*decl));

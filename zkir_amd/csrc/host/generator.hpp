@@ -90,7 +90,7 @@ class Generator {
   std::optional<Expr> gen_un_expr(ExprKind k, size_t depth);
   // extensions
   std::optional<Instruction> gen_constraint_quadratic();
-  Expr gen_linear();
+  Expr gen_linear(bool factor);
   void push_generated(std::vector<Instruction>& out, std::optional<Instruction>&& instr);
 
   Rng rng_;
