@@ -561,6 +561,14 @@ __global__ void zkir_consts_to_mont29_kernel(const uint32_t* __restrict__ src, u
   dst[(size_t)i * 12 + 9] = dst[(size_t)i * 12 + 10] = dst[(size_t)i * 12 + 11] = 0;
 }
 
+// What a single-tape launch starts from: the caller's four result words {0, all ones, 0, 0} and the work counters
+// (64 words) zeroed.  One kernel instead of three memsets: a memset recorded into a HIP graph was seen to write
+// other values on the graph's second replay (ROCm 7.2), a kernel node replays with the arguments it was recorded with.
+__global__ void zkir_init_launch_kernel(uint64_t* result, uint32_t* counters) {
+  if (threadIdx.x < 4 && result) result[threadIdx.x] = threadIdx.x == 1 ? ~0ull : 0ull;
+  if (threadIdx.x < 64) counters[threadIdx.x] = 0;
+}
+
 // constants arrive canonical; rewrite them in Montgomery form in place
 __global__ void zkir_consts_to_mont_kernel(uint32_t* consts, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -707,6 +715,11 @@ hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, uint32_t strands, 
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, interp_entry(variant), strands == 8 ? 2 * kBlock : kBlock, lds_bytes);
   if (e == hipSuccess && *blocks < 1) *blocks = 1;
   return e;
+}
+
+hipError_t launch_init(uint64_t* result_dev, uint32_t* counters_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(zkir_init_launch_kernel, dim3(1), dim3(64), 0, stream, result_dev, counters_dev);
+  return hipGetLastError();
 }
 
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream) {

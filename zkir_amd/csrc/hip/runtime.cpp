@@ -26,6 +26,7 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
                          uint64_t* faults_per_tape, hipStream_t stream);
 hipError_t interp_blocks_per_cu(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots, int* blocks);
 size_t interp_lds_need(int variant, uint32_t lslots, uint32_t strands, uint32_t xslots);
+hipError_t launch_init(uint64_t* result_dev, uint32_t* counters_dev, hipStream_t stream);
 hipError_t launch_consts_to_mont(uint32_t* consts_dev, uint32_t n, hipStream_t stream);
 hipError_t launch_consts_to_mont29(const uint32_t* canonical_dev, uint32_t* dst_dev, uint32_t n, hipStream_t stream);
 size_t interp_slot_bytes(int variant);
@@ -368,14 +369,17 @@ int32_t launch_group(zkir_ctx* ctx, const Group& G, const Plan& P, const TapeDes
   return ZKIR_OK;
 }
 
-// One tape on device buffers.  unsat_dev has 1 entry, stats_dev 2 ({packed first unsat, faults}); both
-// must already be initialised.  The tape's own descriptor (written at upload) is used, so nothing is
+// One tape on device buffers.  unsat_dev points at the caller's four result words {unsat, packed first unsat,
+// faults, spare} (stats_dev at the second), which this call initialises on the stream.  The tape's own descriptor (written at upload) is used, so nothing is
 // copied.  fixed_scratch: null (the context's growable pool and counters) or a fixed region of
 // `fixed_bytes` whose first 8 KiB hold the work counter and the rest slot rows; with it the call
 // allocates nothing.
 int32_t run_one(zkir_ctx* ctx, const DevTape& t, const uint32_t* in_dev, uint64_t N, uint32_t* out_dev, uint64_t* unsat_dev,
                 uint64_t* stats_dev, hipStream_t stream, unsigned char* fixed_scratch, size_t fixed_bytes) {
-  if (N == 0) return ZKIR_OK;
+  if (N == 0) {  // nothing to launch: the result words still start from {0, all ones, 0, 0}
+    HIP_TRY(ctx, zkir::launch_init(unsat_dev, (uint32_t*)ctx->work_counter, stream));
+    return ZKIR_OK;
+  }
   if (N >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "N must be below 2^32");
   Group G;
   G.add(t);
@@ -398,7 +402,7 @@ int32_t run_one(zkir_ctx* ctx, const DevTape& t, const uint32_t* in_dev, uint64_
   }
   rc = chain_stream(ctx, stream);
   if (rc) return rc;
-  HIP_TRY(ctx, hipMemsetAsync(counter, 0, 256, stream));
+  HIP_TRY(ctx, zkir::launch_init(unsat_dev, counter, stream));  // the result words (unsat_dev points at the first) and the counters
   rc = launch_group(ctx, G, P, (const TapeDesc*)t.desc, in_dev, N, out_dev, pool, counter, unsat_dev, stats_dev, nullptr, stream);
   if (rc) return rc;
   return chain_done(ctx, stream);
@@ -691,7 +695,6 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
   if (it->second.hdr.n_inputs && N && !inputs_soa_dev) return fail(ctx, ZKIR_E_INVALID, "inputs required");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(ctx, init_result(result_dev, s));
   return run_one(ctx, it->second, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s, nullptr, 0);
 }
 
@@ -711,8 +714,7 @@ int32_t zkir_eval_batch_dev_noalloc(zkir_ctx* ctx, zkir_tape_id tape, const uint
     if (owner->recorded && owner->ctx != ctx && hipEventQuery(owner->done) == hipErrorNotReady)
       return fail(ctx, ZKIR_E_BUSY, "another context's zkir_eval_batch_dev_noalloc launch is still running on this GPU's scratch array");
   }
-  HIP_TRY(ctx, init_result(result_dev, s));
-  // the counter is cleared by run_one; slot rows need no clearing (a tape writes a slot before it reads it)
+  // the result words and the counter are initialised by run_one; slot rows need no clearing (a tape writes a slot before it reads it)
   const int32_t rc = run_one(ctx, it->second, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s, ctx->static_scratch,
                              (size_t)ZKIR_NOALLOC_SCRATCH_BYTES);
   if (rc == ZKIR_OK && owner && !capturing && owner->done) {
