@@ -325,13 +325,17 @@ int32_t zkir_lower(const zkir_circuit* c, const zkir_lower_options* opts, zkir_t
  * spread over `threads` host threads.  tapes[k] receives the tape, or NULL with status_classes[k] set to the
  * ZKIR_LOWER_* class that refused the circuit (that is a result: the call still returns ZKIR_OK).  cfgs may
  * be NULL (defaults for every circuit), opts may be NULL.  On any other error every tape made so far is
- * freed and the code is returned.  The caller frees the tapes with zkir_tape_free. */
+ * freed and the code is returned.  The caller frees the tapes with zkir_tape_free.
+ * Straight-line configurations (no_loops, no If, max_expr_depth 1, arithmetic_only, quadratic_aware: what a
+ * campaign draws) are lowered while they are generated, without the Circuit in between: the same random
+ * draws, the same tape, the same refusals, at a third of the host time. */
 int32_t zkir_generate_lower_many(const uint64_t* seeds, const zkir_generator_config* cfgs, uint32_t n,
                                  const zkir_lower_options* opts, uint32_t threads, zkir_tape** tapes,
                                  int32_t* status_classes);
 
 /* Thread-seconds zkir_generate_lower_many has spent so far, over all its calls and worker threads of this
- * process, generating circuits and lowering them (a campaign's report of where its host time goes; the
+ * process, generating circuits and lowering them (for circuits whose statements go to lower as they are drawn,
+ * without the circuit being built: drawing plus the pass that makes single-assignment ops, and slot placement) (a campaign's report of where its host time goes; the
  * reference has no timing code: src/main.rs:81-92). */
 int32_t zkir_host_phase_seconds(double* generate_s, double* lower_s);
 
@@ -364,6 +368,11 @@ int32_t zkir_tape_release(zkir_ctx* ctx, zkir_tape_id id);
  * ids; on error no tape of the call is uploaded.  Each id is released on its own. */
 int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hdrs, const void* const* blobs,
                               const size_t* bytes, zkir_tape_id* out);
+
+/* zkir_tape_upload_many for tapes the library itself holds (handles from zkir_lower, zkir_generate_lower_many or
+ * zkir_tape_from_blob): such a tape was made or validated by the library, so the upload does not look at every
+ * op again, which is most of what uploading a campaign's tapes costs. */
+int32_t zkir_tape_upload_handles(zkir_ctx* ctx, uint32_t n, const zkir_tape* const* tapes, zkir_tape_id* out);
 
 /* Evaluate one tape for N input vectors; all pointers are HOST memory.
  *   inputs_soa   [n_inputs][8][N]   (may be NULL when n_inputs == 0)

@@ -116,3 +116,75 @@ def test_batched_generate_and_lower_equals_one_by_one():
         assert False, "expected an error"
     except z.ZkirError as e:
         assert e.code == z.E_INVALID
+
+
+def test_circuits_lowered_while_generated_give_the_tape_of_generate_then_lower():
+    """Straight-line campaign configurations never build the Circuit: zkir_generate_lower_many hands every statement
+    to lower as it is drawn.  Same draws, same tape bytes, same io maps, same refusals as Generator(seed, cfg).generate()
+    followed by Lowerer(circuit, opts).lower(), over seeds, sizes, every knob such a configuration has and the
+    placement options; configurations that need the circuit (loops, If, deep expressions, every operator) still
+    go through it and agree as well."""
+    import random
+    rnd = random.Random(5)
+    seeds, cfgs = [], []
+    for k in range(260):
+        g = z.default_generator_config()
+        g.min_instructions = rnd.choice([0, 1, 5, 40, 150, 600])
+        g.max_instructions = g.min_instructions + rnd.choice([0, 0, 7, 300])
+        g.no_loops, g.quadratic_aware, g.arithmetic_only = 1, 1, 1
+        g.forced_inputs = rnd.choice([0, 0, 1, 8])
+        g.inputs_readable = rnd.choice([0, 1, 1])
+        g.safe_array_index = rnd.choice([0, 1, 1])
+        g.signal_window = rnd.choice([0, 0, 3])
+        g.max_linear_terms = rnd.choice([0, 1, 2])
+        g.signal_factors = rnd.choice([0, 1])
+        g.max_array_len = rnd.choice([1, 10, 64])
+        g.statement_budget = rnd.choice([10, 10, 1, 3])
+        g.name_len = rnd.choice([8, 1, 30])
+        if k % 13 == 0:    # these need the circuit built first
+            g.no_loops = 0
+        elif k % 13 == 1:
+            g.arithmetic_only = 0
+        elif k % 13 == 2:
+            g.max_expr_depth = 2
+        elif k % 13 == 3:
+            g.enable_if = 2
+        seeds.append(rnd.choice([1, 2, 3, 2**64 - 1, rnd.getrandbits(64) | 1]))
+        cfgs.append(g)
+    n_refused = n_tapes = 0
+    for variant in range(3):
+        o = z.default_lower_options()
+        o.max_iterations = 300
+        if variant == 1:
+            o.reorder, o.window_cache, o.order_ops, o.n_lslots = 0, 0, 0, 4
+        if variant == 2:
+            o.strands, o.reorder = 4, 0
+        expect = []
+        for s, g in zip(seeds, cfgs):
+            c = z.Generator(s, g).generate()
+            try:
+                t = z.Lowerer(c, o).lower()
+                expect.append((0, bytes(t.hdr), t.blob(), t.io_map(0), t.io_map(1)))
+                n_tapes += 1
+            except z.LowerRejected as e:
+                expect.append((e.status_class, None, None, None, None))
+                n_refused += 1
+        got = z.generate_lower_many(seeds, cfgs, o, 4)
+        for k, ((cls, t), want) in enumerate(zip(got, expect)):
+            have = (cls, bytes(t.hdr) if t else None, t.blob() if t else None, t.io_map(0) if t else None, t.io_map(1) if t else None)
+            assert have == want, (variant, k, seeds[k], cls, want[0])
+    assert n_refused > 20 and n_tapes > 300
+    # the switch that turns the short cut off (a test aid) gives the same tapes as well
+    import subprocess
+    import sys
+    code = ("import zkir_amd as z\nfrom zkir_amd import campaign\nimport hashlib\n"
+            "ids=list(range(60))\nmade=z.generate_lower_many([campaign.circuit_seed(3,c) for c in ids],[campaign.campaign_config(c,16,200) for c in ids],None,2)\n"
+            "print(hashlib.sha256(b''.join(t.blob() for _,t in made if t)).hexdigest())")
+    import os
+    outs = []
+    for env in ({}, {"ZKIR_NO_FUSED": "1"}):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert p.returncode == 0, p.stderr[-1000:]
+        outs.append(p.stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0]) == 64

@@ -92,6 +92,7 @@ def _load():
         "zkir_tape_upload": [c_void_p, P(TapeHdr), c_void_p, c_size_t, P(c_uint32)],
         "zkir_tape_release": [c_void_p, c_uint32],
         "zkir_tape_upload_many": [c_void_p, c_uint32, P(TapeHdr), P(c_void_p), P(c_size_t), P(c_uint32)],
+        "zkir_tape_upload_handles": [c_void_p, c_uint32, P(c_void_p), P(c_uint32)],
         "zkir_eval_batch": [c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, P(c_uint64), P(c_uint32)],
         "zkir_eval_batch_dev": [c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p],
         "zkir_eval_multi": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, P(c_uint64)],
@@ -363,14 +364,9 @@ class Context:
         n = len(tapes)
         if n == 0:
             return []
-        hdrs = (TapeHdr * n)(*[t.hdr for t in tapes])
-        blobs, sizes = (c_void_p * n)(), (c_size_t * n)()
-        for k, t in enumerate(tapes):  # pointers into the tapes' own memory: nothing is copied on the host here
-            p, sz = c_void_p(), c_size_t()
-            _host_check(lib.zkir_tape_blob(t._h, byref(p), byref(sz)))
-            blobs[k], sizes[k] = p.value, sz.value
+        handles = (c_void_p * n)(*[t._h for t in tapes])  # the library's own tapes: validated when they were made
         ids = (c_uint32 * n)()
-        self._check(lib.zkir_tape_upload_many(self._h, n, hdrs, blobs, sizes, ids))
+        self._check(lib.zkir_tape_upload_handles(self._h, n, handles, ids))
         for k, t in enumerate(tapes):
             self._tapes[ids[k]] = (t.hdr.n_inputs, t.hdr.n_outputs)
         return list(ids)

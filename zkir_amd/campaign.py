@@ -9,6 +9,8 @@ Sharding: circuit i belongs to rank i mod world; ranks never exchange circuit da
 The only communication is at the end: one all-reduce of the counters and one
 all-gather of the (padded) lists of divergent circuit ids.
 """
+import math
+
 import numpy as np
 
 from . import api
@@ -25,14 +27,20 @@ def shard(n_circuits, rank, world):
     return range(rank, n_circuits, world)
 
 
+_DEFAULT_CONFIG_BYTES = None
+
+
 def campaign_config(circuit_id, min_constraints=64, max_constraints=4096):
     """Generator knobs for campaign circuits: straight-line arithmetic circuits whose
     constraint count is spread log-uniformly over [min, max] by the circuit id."""
-    g = api.default_generator_config()
+    global _DEFAULT_CONFIG_BYTES
+    if _DEFAULT_CONFIG_BYTES is None:
+        _DEFAULT_CONFIG_BYTES = bytes(api.default_generator_config())
+    g = api.GeneratorConfig.from_buffer_copy(_DEFAULT_CONFIG_BYTES)  # (one library call per circuit adds up over a campaign)
     # about one statement in four is a constraint
-    lo, hi = np.log(min_constraints * 4.0), np.log(max_constraints * 4.0)
+    lo, hi = math.log(min_constraints * 4.0), math.log(max_constraints * 4.0)
     u = ((circuit_id * 2654435761) % 4096) / 4095.0
-    n = int(round(float(np.exp(lo + (hi - lo) * u))))
+    n = int(round(math.exp(lo + (hi - lo) * u)))
     g.min_instructions = g.max_instructions = n
     g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = 8, 1, 1, 1
     g.no_loops, g.safe_array_index = 1, 1

@@ -17,6 +17,7 @@
 #include "../../../include/zkir_hip.h"
 #include "device_structs.h"
 #include "tape_check.h"
+#include "../host/lower.hpp"  // zkir_tape: the handle zkir_lower and zkir_tape_from_blob hand out
 
 namespace zkir {
 hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tapes, uint32_t passes_per_tape,
@@ -98,6 +99,8 @@ struct zkir_ctx {
   bool desc_copy_recorded[2] = {false, false};
   int desc_turn = 0;
   unsigned char* static_scratch = nullptr;  // this device's copy of the file-scope scratch array below
+  void* up_stage = nullptr;  // pinned host memory a batch of tapes is gathered in before its one copy to the device
+  size_t up_stage_bytes = 0;
 };
 
 namespace {
@@ -565,6 +568,7 @@ int32_t zkir_ctx_destroy(zkir_ctx* ctx) {
     if (b) (void)hipFree(b);
   for (void* b : ctx->pipe_stage)
     if (b) (void)hipHostFree(b);
+  if (ctx->up_stage) (void)hipHostFree(ctx->up_stage);
   for (hipEvent_t ev : ctx->pipe_done)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->pipe_stream) (void)hipStreamDestroy(ctx->pipe_stream);
@@ -580,15 +584,45 @@ int32_t zkir_tape_upload(zkir_ctx* ctx, const zkir_tape_hdr* hdr, const void* bl
   return zkir_tape_upload_many(ctx, 1, hdr, blobs, &bytes, out);
 }
 
+static int32_t upload_impl(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hdrs, const void* const* blobs,
+                           const size_t* bytes, zkir_tape_id* out, bool validated);
+
 int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hdrs, const void* const* blobs,
                               const size_t* bytes, zkir_tape_id* out) {
   if (!ctx || (n && (!hdrs || !blobs || !bytes || !out))) return ZKIR_E_INVALID;
   if (n == 0) return ZKIR_OK;
+  return upload_impl(ctx, n, hdrs, blobs, bytes, out, false);
+}
+
+int32_t zkir_tape_upload_handles(zkir_ctx* ctx, uint32_t n, const zkir_tape* const* tapes, zkir_tape_id* out) {
+  if (!ctx || (n && (!tapes || !out))) return ZKIR_E_INVALID;
+  if (n == 0) return ZKIR_OK;
+  std::vector<zkir_tape_hdr> hdrs;
+  std::vector<const void*> blobs;
+  std::vector<size_t> bytes;
+  try {
+    hdrs.resize(n);
+    blobs.resize(n);
+    bytes.resize(n);
+  } catch (const std::bad_alloc&) {
+    return fail(ctx, ZKIR_E_NOMEM, "host bookkeeping");
+  }
+  for (uint32_t k = 0; k < n; k++) {
+    if (!tapes[k]) return fail(ctx, ZKIR_E_INVALID, "null tape handle");
+    hdrs[k] = tapes[k]->tape.hdr;
+    blobs[k] = tapes[k]->tape.blob.data();
+    bytes[k] = tapes[k]->tape.blob.size();
+  }
+  // a tape handle comes from lower or from zkir_tape_from_blob, which validated it: no second look at every op
+  return upload_impl(ctx, n, hdrs.data(), blobs.data(), bytes.data(), out, true);
+}
+
+static int32_t upload_impl(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hdrs, const void* const* blobs,
+                           const size_t* bytes, zkir_tape_id* out, bool validated) {
   std::string why;
   // device layout of the batch: every tape's ops, then (256-byte aligned) every tape's constants, so that
   // one kernel converts all constants, then (256-byte aligned) one descriptor per tape: the tape evaluated alone
   std::vector<DevTape> tapes;
-  std::vector<char> staging;
   size_t ops_total = 0, consts_total = 0;
   try {
     tapes.resize(n);
@@ -596,7 +630,7 @@ int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hd
     return fail(ctx, ZKIR_E_NOMEM, "host bookkeeping");
   }
   for (uint32_t k = 0; k < n; k++) {
-    if (!zkir::check_tape(hdrs[k], blobs[k], bytes[k], &why))
+    if (!validated && !zkir::check_tape(hdrs[k], blobs[k], bytes[k], &why))
       return fail(ctx, ZKIR_E_INVALID, (n > 1 ? "bad tape " + std::to_string(k) + ": " : std::string("bad tape: ")) + why);
     DevTape& t = tapes[k];
     t.hdr = hdrs[k];
@@ -621,33 +655,69 @@ int32_t zkir_tape_upload_many(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hd
   const size_t consts29_off = (staged + 255) & ~(size_t)255;       // written by the device: 48 bytes per constant
   const size_t total = consts29_off + consts_total / 32 * 48;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  try {
-    staging.resize(staged);
-  } catch (const std::bad_alloc&) {
-    return fail(ctx, ZKIR_E_NOMEM, "host staging buffer");
+  // the batch is gathered in pinned memory the context keeps (a copy from it runs at the link's rate and needs no
+  // second staging inside the runtime); the previous upload's copy was synchronous, so the buffer is free
+  if (ctx->up_stage_bytes < staged) {
+    if (ctx->up_stage) (void)hipHostFree(ctx->up_stage);
+    ctx->up_stage = nullptr;
+    ctx->up_stage_bytes = 0;
+    const size_t sz = std::max<size_t>(staged + staged / 4, (size_t)1 << 20);
+    if (hipHostMalloc(&ctx->up_stage, sz, hipHostMallocDefault) != hipSuccess) return fail(ctx, ZKIR_E_NOMEM, "pinned staging buffer");
+    ctx->up_stage_bytes = sz;
   }
+  char* const staging = (char*)ctx->up_stage;
   void* base = nullptr;
   int slab = -1;
   size_t mark = 0;
   int32_t rc = arena_alloc(ctx, total, &base, &slab, &mark);
   if (rc) return rc;
+  std::vector<size_t> ops_at, consts_at;
+  try {
+    ops_at.resize(n);
+    consts_at.resize(n);
+  } catch (const std::bad_alloc&) {
+    arena_rollback(ctx, slab, mark, total);
+    return fail(ctx, ZKIR_E_NOMEM, "host bookkeeping");
+  }
   size_t o = 0, c = consts_off;
   for (uint32_t k = 0; k < n; k++) {
-    const size_t ob = (size_t)hdrs[k].n_ops * sizeof(zkir_op), cb = (size_t)hdrs[k].n_consts * 32;
-    if (ob) std::memcpy(staging.data() + o, blobs[k], ob);
-    if (cb) std::memcpy(staging.data() + c, (const char*)blobs[k] + ob, cb);
+    ops_at[k] = o;
+    consts_at[k] = c;
     tapes[k].ops = (char*)base + o;
     tapes[k].consts = (char*)base + c;
     tapes[k].consts29 = (char*)base + consts29_off + (c - consts_off) / 32 * 48;
     tapes[k].desc = (char*)base + descs_off + (size_t)k * sizeof(TapeDesc);
     tapes[k].slab = slab;
-    const TapeDesc d = make_desc(tapes[k], 0, 0, 0);
-    std::memcpy(staging.data() + descs_off + (size_t)k * sizeof(TapeDesc), &d, sizeof d);
-    o += ob;
-    c += cb;
+    o += (size_t)hdrs[k].n_ops * sizeof(zkir_op);
+    c += (size_t)hdrs[k].n_consts * 32;
   }
-  // synchronous copy from pageable memory: `staging` may go when it returns
-  hipError_t e = hipMemcpy(base, staging.data(), staging.size(), hipMemcpyHostToDevice);
+  auto gather = [&](uint32_t k0, uint32_t k1) {
+    for (uint32_t k = k0; k < k1; k++) {
+      const size_t ob = (size_t)hdrs[k].n_ops * sizeof(zkir_op), cb = (size_t)hdrs[k].n_consts * 32;
+      if (ob) std::memcpy(staging + ops_at[k], blobs[k], ob);
+      if (cb) std::memcpy(staging + consts_at[k], (const char*)blobs[k] + ob, cb);
+      const TapeDesc d = make_desc(tapes[k], 0, 0, 0);
+      std::memcpy(staging + descs_off + (size_t)k * sizeof(TapeDesc), &d, sizeof d);
+    }
+  };
+  {  // big batches on a few threads: one thread copies at about 10 GB/s
+    const unsigned hw = std::thread::hardware_concurrency();
+    const uint32_t n_threads = staged < ((size_t)16 << 20) ? 1u : std::max(1u, std::min({4u, hw ? hw : 1u, n}));
+    std::vector<std::thread> pool;
+    const uint32_t per = (n + n_threads - 1) / n_threads;
+    try {
+      for (uint32_t t = 1; t < n_threads; t++)
+        if (t * per < n) pool.emplace_back(gather, t * per, std::min(n, (t + 1) * per));
+    } catch (const std::system_error&) {  // fewer helpers than asked for: the rest is done here
+    }
+    const uint32_t started = (uint32_t)pool.size();
+    gather(0, std::min(n, per));
+    for (uint32_t t = started + 1; t < n_threads; t++)
+      if (t * per < n) gather(t * per, std::min(n, (t + 1) * per));
+    for (std::thread& th : pool) th.join();
+  }
+  // synchronous copy: the staging buffer is free again when it returns
+  hipError_t e = hipMemcpy(base, staging, staged, hipMemcpyHostToDevice);
   // both forms of the constants: the 29-bit one is made from the canonical words first, then those are
   // converted in place
   if (e == hipSuccess)

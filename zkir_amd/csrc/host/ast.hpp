@@ -52,6 +52,16 @@ class Arena {
     static_assert(std::is_trivially_destructible<T>::value, "arena nodes are never destroyed");
     return new (alloc(sizeof(T), alignof(T))) T(v);
   }
+  // Forget every node (their memory is reused from the first chunk on): for a caller that builds one statement at
+  // a time and is done with its nodes before the next.
+  void reset() {
+    while (chunks_.size() > 1) {
+      ::operator delete(chunks_.back());
+      chunks_.pop_back();
+    }
+    cur_ = chunks_.empty() ? nullptr : chunks_[0];
+    left_ = chunks_.empty() ? 0 : first_size_;
+  }
   const char* text(const char* s, size_t n) {
     char* p = (char*)alloc(n + 1, 1);
     std::memcpy(p, s, n);
@@ -65,12 +75,13 @@ class Arena {
     if (next_ < (1u << 20)) next_ *= 2;
     if (n < at_least) n = at_least;
     chunks_.push_back((char*)::operator new(n));
+    if (chunks_.size() == 1) first_size_ = n;
     cur_ = chunks_.back();
     left_ = n;
   }
   std::vector<char*> chunks_;
   char* cur_ = nullptr;
-  size_t left_ = 0, next_ = 16384;
+  size_t left_ = 0, next_ = 16384, first_size_ = 0;
 };
 
 // src/ast.rs:3-10

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -81,10 +82,7 @@ int32_t zkir_generate(uint64_t seed, const zkir_generator_config* cfg, zkir_circ
   *out = nullptr;
   return guarded([&]() -> int32_t {
     zkir::GeneratorConfig c = cfg ? *cfg : zkir::default_generator_config();
-    if (c.min_instructions > c.max_instructions || c.max_array_len == 0 || c.loop_body_max == 0 ||
-        c.max_instructions > (1u << 22) || c.name_len == 0 || c.name_len > 64 || c.max_expr_depth > 64 ||
-        c.loop_init_max > c.loop_bound_max)
-      throw std::invalid_argument("generator config out of range");
+    zkir::validate_generator_config(c);
     zkir::Generator g(zkir::Rng::from_seed(seed), c);
     auto* h = new zkir_circuit();
     h->circuit = g.generate();
@@ -218,6 +216,7 @@ int32_t zkir_generate_lower_many(const uint64_t* seeds, const zkir_generator_con
     status_classes[k] = ZKIR_LOWER_OK;
   }
   const zkir::LowerOptions o = opts ? *opts : zkir::default_lower_options();
+  const bool fused = std::getenv("ZKIR_NO_FUSED") == nullptr;  // test aid: set, every circuit is built and then lowered
   std::atomic<uint32_t> next{0};
   std::atomic<int32_t> failed{ZKIR_OK};
   std::mutex error_lock;
@@ -234,17 +233,43 @@ int32_t zkir_generate_lower_many(const uint64_t* seeds, const zkir_generator_con
     for (;;) {
       const uint32_t k = next.fetch_add(1);
       if (k >= n || failed.load() != ZKIR_OK) return;
-      zkir_circuit* c = nullptr;
+      const zkir::GeneratorConfig cfg = cfgs ? cfgs[k] : zkir::default_generator_config();
+      int32_t rc = ZKIR_OK;
       const uint64_t t0 = now_ns();
-      int32_t rc = zkir_generate(seeds[k], cfgs ? &cfgs[k] : nullptr, &c);
-      const uint64_t t1 = now_ns();
-      gen_ns += t1 - t0;
-      if (rc == ZKIR_OK) {
-        rc = zkir_lower(c, &o, &tapes[k], &status_classes[k]);
-        if (rc == ZKIR_E_LOWER) rc = ZKIR_OK;  // a refused circuit is a result, not a failure of the call
+      if (fused && zkir::can_lower_generated(cfg, o)) {
+        // the circuit is never built: its statements go to pass 1 as they are drawn (same draws, same tape)
+        double pass1_s = 0;
+        rc = guarded([&]() -> int32_t {
+          auto* h = new zkir_tape();
+          try {
+            h->tape = zkir::lower_generated(seeds[k], cfg, o, &pass1_s);
+          } catch (const zkir::LowerError& e) {
+            delete h;
+            status_classes[k] = e.status_class;
+            return ZKIR_OK;  // a refused circuit is a result, not a failure of the call
+          } catch (...) {
+            delete h;
+            throw;
+          }
+          tapes[k] = h;
+          return ZKIR_OK;
+        });
+        const uint64_t t1 = now_ns();
+        const uint64_t p1 = std::min<uint64_t>((uint64_t)(pass1_s * 1e9), t1 - t0);
+        gen_ns += p1;            // drawing the circuit and pass 1
+        low_ns += t1 - t0 - p1;  // slot placement
+      } else {
+        zkir_circuit* c = nullptr;
+        rc = zkir_generate(seeds[k], &cfg, &c);
+        const uint64_t t1 = now_ns();
+        gen_ns += t1 - t0;
+        if (rc == ZKIR_OK) {
+          rc = zkir_lower(c, &o, &tapes[k], &status_classes[k]);
+          if (rc == ZKIR_E_LOWER) rc = ZKIR_OK;  // a refused circuit is a result, not a failure of the call
+        }
+        zkir_circuit_free(c);
+        low_ns += now_ns() - t1;
       }
-      zkir_circuit_free(c);
-      low_ns += now_ns() - t1;
       if (rc != ZKIR_OK) {
         std::lock_guard<std::mutex> g(error_lock);
         if (failed.load() == ZKIR_OK) {

@@ -23,40 +23,14 @@ GeneratorConfig default_generator_config() {
   return c;
 }
 
-// ---- ScopeStack (generator.rs:48-115) ----
-void Generator::OrderedSet::resize(size_t n) {
-  if (n < flag_.size()) {
-    for (size_t p = n; p < flag_.size(); p++) set(p, false);
-    flag_.resize(n);
-    return;
-  }
-  flag_.resize(n, 0);
-  if (n + 1 > tree_.size()) {  // grow to the next power of two and rebuild
-    size_t cap = 16;
-    while (cap < n + 1) cap *= 2;
-    tree_.assign(cap, 0);
-    for (size_t p = 0; p < flag_.size(); p++)
-      if (flag_[p])
-        for (size_t i = p + 1; i < tree_.size(); i += i & (~i + 1)) tree_[i] += 1;
-  }
-}
-void Generator::OrderedSet::set(size_t pos, bool on) {
-  if (pos >= flag_.size() || (bool)flag_[pos] == on) return;
-  flag_[pos] = on;
-  count_ += on ? 1 : (size_t)-1;
-  for (size_t i = pos + 1; i < tree_.size(); i += i & (~i + 1)) tree_[i] += on ? 1 : -1;
-}
-size_t Generator::OrderedSet::select(size_t k) const {
-  size_t pos = 0;
-  int64_t rem = (int64_t)k + 1;
-  for (size_t step = tree_.size() / 2; step > 0; step /= 2)
-    if (pos + step < tree_.size() && tree_[pos + step] < rem) {
-      pos += step;
-      rem -= tree_[pos];
-    }
-  return pos;  // 0-based position
+void validate_generator_config(const GeneratorConfig& c) {
+  if (c.min_instructions > c.max_instructions || c.max_array_len == 0 || c.loop_body_max == 0 ||
+      c.max_instructions > (1u << 22) || c.name_len == 0 || c.name_len > 64 || c.max_expr_depth > 64 ||
+      c.loop_init_max > c.loop_bound_max)
+    throw std::invalid_argument("generator config out of range");
 }
 
+// ---- ScopeStack (generator.rs:48-115) ----
 void Generator::ScopeStack::refresh(size_t pos) {
   const Variable& v = flat[pos];
   const bool field = !v.var_type.is_array;

@@ -8,12 +8,15 @@
 
 #include "../../../include/zkir_hip.h"
 #include "ast.hpp"
+#include "ordered_set.hpp"
 #include "rng.hpp"
 
 namespace zkir {
 
 using GeneratorConfig = zkir_generator_config;
 GeneratorConfig default_generator_config();
+// throws std::invalid_argument for a configuration outside what the generator takes
+void validate_generator_config(const GeneratorConfig& c);
 
 class Generator {
  public:
@@ -48,18 +51,6 @@ class Generator {
   // circuit size.  The same answers, in the same scope order, are kept here incrementally:
   // plain position lists for the static categories, and order-statistic (Fenwick) sets for
   // the ones that change when a variable becomes initialised.
-  class OrderedSet {
-   public:
-    void resize(size_t n);          // positions 0..n-1 exist; new ones are absent
-    void set(size_t pos, bool on);
-    bool test(size_t pos) const { return pos < flag_.size() && flag_[pos]; }
-    size_t count() const { return count_; }
-    size_t select(size_t k) const;  // position of the k-th (0-based) member
-   private:
-    std::vector<uint8_t> flag_;
-    std::vector<int32_t> tree_;     // Fenwick tree over flag_, 1-based, capacity a power of two
-    size_t count_ = 0;
-  };
   struct ScopeStack {
     std::vector<Variable> flat;        // every variable in scope, outermost scope first
     std::vector<size_t> scope_begin;   // first position of each open scope

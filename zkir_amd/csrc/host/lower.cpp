@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -16,6 +17,9 @@
 #include <unordered_map>
 
 #include "fr_host.hpp"
+#include "generator.hpp"
+#include "ordered_set.hpp"
+#include "rng.hpp"
 
 namespace zkir {
 
@@ -76,19 +80,26 @@ struct Quad {
 };
 
 struct Cells {
-  const Variable* var = nullptr;  // in circuit.variables
+  size_t id = 0;
+  VariableRole role;
+  bool is_array = false;
+  size_t type_len = 0;                // Array(type_len)
+  const std::string* name = nullptr;  // in circuit.variables; null for circuits streamed from the generator (no names)
   size_t off = 0, len = 0;  // its elements are vals_[off .. off+len) once it has been declared
   size_t io_offset = 0;  // signals: first element in the input / output vector
   int declared = 0;      // times the declaration has executed
 };
 
 struct U256Hash {
-  size_t operator()(const U256& a) const { return (size_t)(a.w[0] * 0x9e3779b97f4a7c15ull ^ a.w[1] ^ (a.w[2] << 7) ^ a.w[3]); }
+  size_t operator()(const U256& a) const {
+    const uint64_t h = (a.w[0] ^ a.w[1] * 0xc2b2ae3d27d4eb4full ^ a.w[2] * 0x165667b19e3779f9ull ^ a.w[3]) * 0x9e3779b97f4a7c15ull;
+    return (size_t)(h ^ h >> 29);
+  }
 };
 
 class Pass1 {
  public:
-  Pass1(const Circuit& c, const LowerOptions& o) : circuit_(c), opts_(o) {
+  explicit Pass1(const LowerOptions& o) : opts_(o) {
     max_ops_ = o.max_ops ? o.max_ops : (1u << 22);
     max_iterations_ = o.max_iterations ? o.max_iterations : (1u << 20);
   }
@@ -100,31 +111,40 @@ class Pass1 {
   size_t n_inputs = 0, n_outputs = 0;
   std::vector<Tape::IoEntry> inputs, outputs;
 
-  void run() {
-    // signal layout: declaration order in circuit.variables, arrays flattened
-    cells_.reserve(circuit_.variables.size());
-    for (const Variable& v : circuit_.variables) {
-      Cells c;
-      c.var = &v;
-      const size_t len = v.var_type.is_array ? v.var_type.len : 1;
-      if (v.role.is_input()) {
-        c.io_offset = n_inputs;
-        inputs.push_back({v.var_ref.id, n_inputs, len});
-        n_inputs += len;
-      } else if (v.role.is_output()) {
-        c.io_offset = n_outputs;
-        outputs.push_back({v.var_ref.id, n_outputs, len});
-        n_outputs += len;
-      }
-      cells_.push_back(std::move(c));
+  // A variable of the circuit, in declaration order.  Signal layout: declaration order, arrays flattened.
+  // Returns its position (what the streaming calls below name it by).
+  size_t add_variable(size_t id, VariableRole role, bool is_array, size_t type_len, const std::string* name) {
+    Cells c;
+    c.id = id;
+    c.role = role;
+    c.is_array = is_array;
+    c.type_len = type_len;
+    c.name = name;
+    const size_t len = is_array ? type_len : 1;
+    if (role.is_input()) {
+      c.io_offset = n_inputs;
+      inputs.push_back({id, n_inputs, len});
+      n_inputs += len;
+    } else if (role.is_output()) {
+      c.io_offset = n_outputs;
+      outputs.push_back({id, n_outputs, len});
+      n_outputs += len;
+      output_written_.resize(n_outputs, false);
     }
+    cells_.push_back(c);
+    return cells_.size() - 1;
+  }
+
+  void run(const Circuit& circuit) {
+    cells_.reserve(circuit.variables.size());
+    for (const Variable& v : circuit.variables) add_variable(v.var_ref.id, v.role, v.var_type.is_array, v.var_type.len, &v.name);
     // id -> position in cells_: a table when the ids are dense (the generator numbers them 0, 1, 2, ...), else a map
     size_t max_id = 0;
-    for (const Variable& v : circuit_.variables) max_id = std::max(max_id, v.var_ref.id);
+    for (const Variable& v : circuit.variables) max_id = std::max(max_id, v.var_ref.id);
     const bool dense = max_id < 4 * cells_.size() + 1024;
     if (dense) pos_of_id_.assign(max_id + 1, -1);
     for (size_t k = 0; k < cells_.size(); k++) {
-      const size_t id = cells_[k].var->var_ref.id;
+      const size_t id = cells_[k].id;
       if (dense) {
         if (pos_of_id_[id] >= 0) fail(ZKIR_LOWER_BAD_AST, "duplicate variable id");
         pos_of_id_[id] = (int32_t)k;
@@ -133,24 +153,76 @@ class Pass1 {
       }
     }
     dense_ids_ = dense;
-    output_written_.assign(n_outputs, false);
-    exec_block(circuit_.instructions);
-    // every output element is defined: the ones nothing constrained read as 0
+    exec_block(circuit.instructions);
+    finish();
+  }
+
+  // every output element is defined: the ones nothing constrained read as 0
+  void finish() {
     stmt_begin.push_back((uint32_t)ops.size());
     for (size_t k = 0; k < n_outputs; k++)
       if (!output_written_[k]) emit({ZKIR_OP_OUTPUT, (Ref)k, const_of(U256()), kNoRef});
   }
 
+  // ---- one statement at a time, for a caller that makes the circuit as it goes (variables by position) ----
+  void stream_declare(size_t pos, const Expr* default_value) {
+    note_statement();
+    declare_cell(cells_[pos], default_value);
+  }
+  void stream_assign(size_t pos, const Expr& value) {
+    note_statement();
+    assign_cell(cells_[pos], value);
+  }
+  void stream_array_assign(size_t pos, const Expr& index, const Expr& value) {
+    note_statement();
+    array_assign_cell(cells_[pos], index, value);
+  }
+  void stream_constrain(size_t pos, const Expr& value) {
+    note_statement();
+    constrain_cell(cells_[pos], std::nullopt, value);
+  }
+  void stream_ids_are_positions() { ids_are_positions_ = true; }
+  void reserve_for(size_t n_statements) {  // a circuit of about this many statements is coming
+    cells_.reserve(n_statements + 32);
+    vals_.reserve(n_statements * 3 + 64);
+    ops.reserve(n_statements * 3 + 64);
+    stmt_begin.reserve(n_statements + 8);
+    consts.reserve(n_statements + 64);
+    quads_.reserve(n_statements + 8);
+  }
+
  private:
   [[noreturn]] void fail(int32_t cls, const std::string& m) { throw LowerError(cls, m); }
+  static std::string name_of(const Cells& c) { return c.name ? *c.name : "#" + std::to_string(c.id); }
+  void note_statement() {
+    if (stmt_begin.empty() || stmt_begin.back() != ops.size()) stmt_begin.push_back((uint32_t)ops.size());
+  }
 
+  // the pool holds every value once: an open-addressing table of pool indices (most constants of a generated
+  // circuit are fresh 64-bit draws, so a node-per-entry map spends its time allocating)
   Ref const_of(const U256& v) {
-    auto it = const_ids_.find(v);
-    if (it != const_ids_.end()) return const_ref(it->second);
+    if ((consts.size() + 1) * 2 > const_table_.size()) grow_const_table();
+    const size_t mask = const_table_.size() - 1;
+    size_t at = U256Hash()(v) & mask;
+    for (;; at = (at + 1) & mask) {
+      const uint32_t e = const_table_[at];
+      if (e == UINT32_MAX) break;
+      if (consts[e] == v) return const_ref(e);
+    }
     const uint32_t id = (uint32_t)consts.size();
     consts.push_back(v);
-    const_ids_[v] = id;
+    const_table_[at] = id;
     return const_ref(id);
+  }
+  void grow_const_table() {
+    size_t cap = std::max<size_t>(64, const_table_.size() * 2);
+    while (cap < (consts.size() + 1) * 2) cap *= 2;
+    const_table_.assign(cap, UINT32_MAX);
+    for (uint32_t e = 0; e < consts.size(); e++) {
+      size_t at = U256Hash()(consts[e]) & (cap - 1);
+      while (const_table_[at] != UINT32_MAX) at = (at + 1) & (cap - 1);
+      const_table_[at] = e;
+    }
   }
   void emit(const SOp& op) {
     if (ops.size() >= max_ops_) fail(ZKIR_LOWER_LOOP_CAP, "tape longer than the op cap");
@@ -175,7 +247,9 @@ class Pass1 {
   }
 
   Cells& cells_of(const VarRef& r) {
-    if (dense_ids_) {
+    if (ids_are_positions_) {
+      if (r.id < cells_.size()) return cells_[r.id];
+    } else if (dense_ids_) {
       if (r.id < pos_of_id_.size() && pos_of_id_[r.id] >= 0) return cells_[(size_t)pos_of_id_[r.id]];
     } else {
       auto it = pos_of_sparse_id_.find(r.id);
@@ -186,18 +260,18 @@ class Pass1 {
 
   Val read_var(const VarRef& r) {
     Cells& c = cells_of(r);
-    if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "variable " + c.var->name + " used before its declaration");
+    if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "variable " + name_of(c) + " used before its declaration");
     size_t k = 0;
-    if (c.var->var_type.is_array) {
-      if (!r.idx) fail(ZKIR_LOWER_BAD_AST, "array " + c.var->name + " referenced without an index");
-      if (*r.idx >= c.len) fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var->name);
+    if (c.is_array) {
+      if (!r.idx) fail(ZKIR_LOWER_BAD_AST, "array " + name_of(c) + " referenced without an index");
+      if (*r.idx >= c.len) fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + name_of(c));
       k = *r.idx;
     } else if (r.idx) {
-      fail(ZKIR_LOWER_BAD_AST, "index on the scalar " + c.var->name);
+      fail(ZKIR_LOWER_BAD_AST, "index on the scalar " + name_of(c));
     }
     Val& v = vals_[c.off + k];
-    if (!v.assigned) fail(ZKIR_LOWER_UNINIT_SIGNAL, "signal " + c.var->name + " read before it is assigned");
-    if (c.var->role.is_input() && v.ref == kNoRef) {
+    if (!v.assigned) fail(ZKIR_LOWER_UNINIT_SIGNAL, "signal " + name_of(c) + " read before it is assigned");
+    if (c.role.is_input() && v.ref == kNoRef) {
       // first read of this input element: load it (and convert it) once
       const Ref x = n_values++;
       emit({ZKIR_OP_INPUT, x, (Ref)(c.io_offset + k), kNoRef});
@@ -380,10 +454,10 @@ class Pass1 {
   }
 
   // ---- statements ----
-  void declare(const Instruction& ins) {
-    Cells& c = cells_of(ins.var.var_ref);
-    const size_t len = c.var->var_type.is_array ? c.var->var_type.len : 1;
-    if (c.var->role.is_signal && c.declared) fail(ZKIR_LOWER_DOUBLE_ASSIGN, "signal " + c.var->name + " declared again by a loop");
+  void declare(const Instruction& ins) { declare_cell(cells_of(ins.var.var_ref), ins.default_value); }
+  void declare_cell(Cells& c, const Expr* default_value) {
+    const size_t len = c.is_array ? c.type_len : 1;
+    if (c.role.is_signal && c.declared) fail(ZKIR_LOWER_DOUBLE_ASSIGN, "signal " + name_of(c) + " declared again by a loop");
     c.declared++;
     if (c.len != len) {  // first execution of the declaration: its elements go at the end of vals_
       c.off = vals_.size();
@@ -392,39 +466,39 @@ class Pass1 {
     }
     Val* cell = vals_.data() + c.off;
     for (size_t k = 0; k < len; k++) cell[k] = Val();
-    if (c.var->role.is_local()) {
+    if (c.role.is_local()) {
       for (size_t k = 0; k < len; k++) cell[k] = known_val(U256());  // circom variables start at 0
-    } else if (c.var->role.is_input()) {
+    } else if (c.role.is_input()) {
       for (size_t k = 0; k < len; k++) {
         cell[k].assigned = true;
         cell[k].deg = kLinear;
         cell[k].from_signal = true;
       }
     }
-    if (ins.default_value) {
-      if (!c.var->role.is_local() || c.var->var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "default value on " + c.var->name);
-      Val d = eval(*ins.default_value);
+    if (default_value) {
+      if (!c.role.is_local() || c.is_array) fail(ZKIR_LOWER_BAD_AST, "default value on " + name_of(c));
+      Val d = eval(*default_value);
       vals_[c.off] = std::move(d);
     }
   }
 
-  void assign(const Instruction& ins) {
-    Cells& c = cells_of(ins.target);
-    if (!c.var->role.is_local() || c.var->var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "Assign target must be a local field");
+  void assign(const Instruction& ins) { assign_cell(cells_of(ins.target), *ins.value); }
+  void assign_cell(Cells& c, const Expr& value) {
+    if (!c.role.is_local() || c.is_array) fail(ZKIR_LOWER_BAD_AST, "Assign target must be a local field");
     if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "assignment before declaration");
-    Val v = eval(*ins.value);
+    Val v = eval(value);
     vals_[c.off] = std::move(v);
   }
 
-  void array_assign(const Instruction& ins) {
-    Cells& c = cells_of(ins.target);
-    if (!c.var->role.is_local() || !c.var->var_type.is_array) fail(ZKIR_LOWER_BAD_AST, "ArrayAssign target must be a local array");
+  void array_assign(const Instruction& ins) { array_assign_cell(cells_of(ins.target), *ins.index, *ins.value); }
+  void array_assign_cell(Cells& c, const Expr& index, const Expr& value) {
+    if (!c.role.is_local() || !c.is_array) fail(ZKIR_LOWER_BAD_AST, "ArrayAssign target must be a local array");
     if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "assignment before declaration");
-    Val idx = eval(*ins.index);
+    Val idx = eval(index);
     if (!idx.known || idx.from_signal) fail(ZKIR_LOWER_UNKNOWN_CONTROL, "array index depends on a signal");
     if (idx.value.w[1] | idx.value.w[2] | idx.value.w[3] || idx.value.w[0] >= c.len)
-      fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var->name);
-    Val v = eval(*ins.value);
+      fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + name_of(c));
+    Val v = eval(value);
     vals_[c.off + (size_t)idx.value.w[0]] = std::move(v);
   }
 
@@ -441,22 +515,22 @@ class Pass1 {
     return acc;
   }
 
-  void constrain(const Instruction& ins) {
-    Cells& c = cells_of(ins.target);
-    if (!c.var->role.is_output()) fail(ZKIR_LOWER_BAD_AST, "Constraint target must be an output signal");
+  void constrain(const Instruction& ins) { constrain_cell(cells_of(ins.target), ins.target.idx, *ins.value); }
+  void constrain_cell(Cells& c, const std::optional<size_t>& target_idx, const Expr& value) {
+    if (!c.role.is_output()) fail(ZKIR_LOWER_BAD_AST, "Constraint target must be an output signal");
     if (!c.declared) fail(ZKIR_LOWER_BAD_AST, "constraint before declaration");
     size_t k = 0;
-    if (c.var->var_type.is_array) {
-      if (!ins.target.idx) fail(ZKIR_LOWER_BAD_AST, "array signal constrained without an index");
-      if (*ins.target.idx >= c.len) fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + c.var->name);
-      k = *ins.target.idx;
+    if (c.is_array) {
+      if (!target_idx) fail(ZKIR_LOWER_BAD_AST, "array signal constrained without an index");
+      if (*target_idx >= c.len) fail(ZKIR_LOWER_OOB_INDEX, "index out of bounds on " + name_of(c));
+      k = *target_idx;
     }
-    if (vals_[c.off + k].assigned) fail(ZKIR_LOWER_DOUBLE_ASSIGN, "signal " + c.var->name + " assigned twice");
-    Val v = eval(*ins.value);
-    if (v.deg == kNonQuadratic) fail(ZKIR_LOWER_NON_QUADRATIC, "non quadratic constraint on " + c.var->name);
+    if (vals_[c.off + k].assigned) fail(ZKIR_LOWER_DOUBLE_ASSIGN, "signal " + name_of(c) + " assigned twice");
+    Val v = eval(value);
+    if (v.deg == kNonQuadratic) fail(ZKIR_LOWER_NON_QUADRATIC, "non quadratic constraint on " + name_of(c));
     // `<==` is `<--` followed by `===`: the signal takes the value, then A*B == C is checked
     const Ref out = ref_of(v);
-    const size_t out_index = cells_of(ins.target).io_offset + k;
+    const size_t out_index = c.io_offset + k;
     emit({ZKIR_OP_OUTPUT, (Ref)out_index, out, kNoRef});
     output_written_[out_index] = true;
     const Ref one = const_of(U256::from_u64(1));
@@ -488,9 +562,7 @@ class Pass1 {
   }
 
   void exec(const Instruction& ins) {
-    if (ins.kind != InstrKind::If && ins.kind != InstrKind::For && ins.kind != InstrKind::While &&
-        (stmt_begin.empty() || stmt_begin.back() != ops.size()))
-      stmt_begin.push_back((uint32_t)ops.size());
+    if (ins.kind != InstrKind::If && ins.kind != InstrKind::For && ins.kind != InstrKind::While) note_statement();
     switch (ins.kind) {
       case InstrKind::VarDecl: declare(ins); return;
       case InstrKind::Assign: assign(ins); return;
@@ -532,8 +604,8 @@ class Pass1 {
     if (++iterations_ > max_iterations_) fail(ZKIR_LOWER_LOOP_CAP, "loop trip cap exceeded");
   }
 
-  const Circuit& circuit_;
   LowerOptions opts_;
+  bool ids_are_positions_ = false;
   size_t max_ops_;
   uint64_t max_iterations_;
   std::vector<Cells> cells_;  // one per circuit variable, in declaration order
@@ -542,7 +614,7 @@ class Pass1 {
   std::vector<int32_t> pos_of_id_;
   std::unordered_map<size_t, uint32_t> pos_of_sparse_id_;
   bool dense_ids_ = true;
-  std::unordered_map<U256, uint32_t, U256Hash> const_ids_;
+  std::vector<uint32_t> const_table_;  // open addressing: pool index or UINT32_MAX
   std::vector<bool> output_written_;
   uint64_t iterations_ = 0;
   int eval_depth_ = 0, block_depth_ = 0;
@@ -710,11 +782,21 @@ StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uin
   auto defines = [](const SOp& o) {
     return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP && o.code != ZKIR_OP_BARRIER;
   };
-  std::vector<int64_t> def_at(nv, -1);
-  std::vector<int64_t> next_def(n + 2, (int64_t)n);
+  // The arrays of this function keep their memory from call to call (per thread): a campaign lowers thousands of
+  // circuits per second and thread, and fresh megabytes per circuit are mostly page faults.
+  static thread_local struct {
+    std::vector<int64_t> def_at, next_def, resident_until;
+    std::vector<uint32_t> n_uses, use_pos, fill, cursor, lslot, gslot;
+    std::vector<int32_t> l_dies_head, l_dies_next, g_dies_head, g_dies_next;
+  } W;
+  std::vector<int64_t>& def_at = W.def_at;
+  def_at.assign(nv, -1);
+  std::vector<int64_t>& next_def = W.next_def;
+  next_def.assign(n + 2, (int64_t)n);
   for (int64_t i = (int64_t)n - 1; i >= 0; i--) next_def[i] = defines(op_at(i)) ? i : next_def[i + 1];
   // reads of every value that the accumulator cannot serve, in stream order (compressed rows)
-  std::vector<uint32_t> n_uses(nv + 1, 0);
+  std::vector<uint32_t>& n_uses = W.n_uses;
+  n_uses.assign(nv + 1, 0);
   auto sources = [&](const SOp& o, Ref out[3]) {
     out[0] = out[1] = out[2] = kNoRef;
     if (o.code == ZKIR_OP_INPUT || o.code == ZKIR_OP_NOP || o.code == ZKIR_OP_BARRIER) return;
@@ -737,14 +819,17 @@ StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uin
       }
   }
   for (int32_t v = 0; v < nv; v++) n_uses[v + 1] += n_uses[v];
-  std::vector<uint32_t> use_pos(n_uses[nv]), fill(n_uses.begin(), n_uses.end() - 1);
+  std::vector<uint32_t>&use_pos = W.use_pos, &fill = W.fill;
+  use_pos.assign(n_uses[nv], 0);
+  fill.assign(n_uses.begin(), n_uses.end() - 1);
   for (size_t i = 0; i < n; i++) {
     Ref src[3];
     sources(op_at(i), src);
     for (Ref r : src)
       if (r >= 0 && !in_acc(r, i)) use_pos[fill[r]++] = (uint32_t)i;
   }
-  std::vector<uint32_t> cursor(n_uses.begin(), n_uses.end() - 1);  // per value: its first read not yet passed
+  std::vector<uint32_t>& cursor = W.cursor;  // per value: its first read not yet passed
+  cursor.assign(n_uses.begin(), n_uses.end() - 1);
   const uint32_t kNever = UINT32_MAX;
   auto next_use = [&](int32_t v, size_t from) -> uint32_t {  // first read at or after `from` (calls come with growing `from`)
     uint32_t& c = cursor[v];
@@ -753,7 +838,8 @@ StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uin
   };
 
   // first walk: how long every value stays in the window (the last stream position it may be read there)
-  std::vector<int64_t> resident_until(nv, -1);
+  std::vector<int64_t>& resident_until = W.resident_until;
+  resident_until.assign(nv, -1);
   std::vector<int32_t> resident;
   const size_t window = std::min<size_t>(opts.n_lslots, ZKIR_MAX_LSLOTS);
   for (size_t i = 0; i < n && window; i++) {
@@ -795,10 +881,16 @@ StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uin
   // second walk: slots and ops
   std::fill(cursor.begin(), cursor.end(), 0);
   for (int32_t v = 0; v < nv; v++) cursor[v] = n_uses[v];
-  std::vector<uint32_t> lslot(nv, UINT32_MAX), gslot(nv, UINT32_MAX);
+  std::vector<uint32_t>&lslot = W.lslot, &gslot = W.gslot;
+  lslot.assign(nv, UINT32_MAX);
+  gslot.assign(nv, UINT32_MAX);
   std::vector<uint32_t> free_l, free_g;
   for (uint32_t k = (uint32_t)window; k-- > 0;) free_l.push_back(k);
-  std::vector<int32_t> l_dies_head(n + 1, -1), l_dies_next(nv, -1), g_dies_head(n + 1, -1), g_dies_next(nv, -1);
+  std::vector<int32_t>&l_dies_head = W.l_dies_head, &l_dies_next = W.l_dies_next, &g_dies_head = W.g_dies_head, &g_dies_next = W.g_dies_next;
+  l_dies_head.assign(n + 1, -1);
+  l_dies_next.assign(nv, -1);
+  g_dies_head.assign(n + 1, -1);
+  g_dies_next.assign(nv, -1);
   StreamOut out;
   out.ops.reserve(n + n / 8);
   auto src_operand = [&](Ref r, size_t at) -> uint32_t {
@@ -1118,7 +1210,12 @@ void order_within_statements(std::vector<SOp>& ops, const std::vector<uint32_t>&
     out[1] = o.b;
     if (o.code == ZKIR_OP_CHECK) out[2] = o.dst;
   };
-  std::vector<uint32_t> total_uses(nv, 0);
+  static thread_local struct {
+    std::vector<uint32_t> total_uses;
+    std::vector<int32_t> local_of;
+  } W;  // (memory kept from call to call, per thread)
+  std::vector<uint32_t>& total_uses = W.total_uses;
+  total_uses.assign(nv, 0);
   for (const SOp& o : ops) {
     Ref src[3];
     sources(o, src);
@@ -1127,7 +1224,8 @@ void order_within_statements(std::vector<SOp>& ops, const std::vector<uint32_t>&
   }
   constexpr size_t kMaxBlock = 48;  // longer statements (deep expressions) stay as written
   static thread_local std::unordered_map<uint64_t, std::array<uint8_t, kMaxBlock + 1>> shape_cache;
-  std::vector<int32_t> local_of(nv, -1);  // value -> index within the block of the op that defines it
+  std::vector<int32_t>& local_of = W.local_of;  // value -> index within the block of the op that defines it
+  local_of.assign(nv, -1);
   SOp moved[kMaxBlock];
   for (size_t bi = 0; bi + 1 < begin.size(); bi++) {
     const uint32_t i0 = begin[bi], m = begin[bi + 1] - i0;
@@ -1562,14 +1660,14 @@ void write_tape(Tape& tape, const Pass1& p1, const std::vector<zkir_op>& out_ops
   tape.outputs = p1.outputs;
 }
 
-}  // namespace
-
-Tape Lowerer::lower() {
+void check_options(const LowerOptions& opts_) {
   if (opts_.n_lslots > ZKIR_MAX_LSLOTS) throw LowerError(ZKIR_LOWER_BAD_AST, "n_lslots above ZKIR_MAX_LSLOTS");
   if (opts_.strands != 0 && opts_.strands != ZKIR_STRANDS && opts_.strands != ZKIR_MAX_STRANDS)
     throw LowerError(ZKIR_LOWER_BAD_AST, "strands must be 0, 4 or 8");
-  Pass1 p1(circuit, opts_);
-  p1.run();
+}
+
+// pass 2 and the tape itself, from the single-assignment ops of pass 1
+Tape place_tape(Pass1& p1, const LowerOptions& opts_) {
   if (opts_.order_ops) order_within_statements(p1.ops, p1.stmt_begin, p1.n_values);
   const std::vector<SOp>& ops = p1.ops;
   const size_t n = ops.size();
@@ -1748,6 +1846,269 @@ Tape Lowerer::lower() {
   h.n_mul_ops = so.n_mul;
   write_tape(tape, p1, so.ops, triples);
   return tape;
+}
+
+}  // namespace
+
+
+// ---- generate + lower in one go, for campaigns --------------------------------------------------------------
+// A campaign makes a circuit only to lower it.  For the configurations campaigns draw (no loops, no If, expressions
+// of depth 1, quadratic-aware constraints, + - * only) the generator below makes the same random draws in the same
+// order as Generator (generator.cpp follows src/generator.rs:142-601 function by function; so does this, with the
+// functions named where they are restated) and hands every statement to pass 1 as soon as it exists: no Instruction
+// tree, no Variable objects, no names (their draws are made and dropped), one small arena of expression nodes that
+// is reused from statement to statement.  The tape is bit for bit the one Lowerer(Generator(seed, cfg).generate(),
+// opts).lower() gives (tests/test_host.py compares them over seeds and configurations), a circuit that lower
+// refuses is refused with the same class.
+namespace {
+
+class StraightLine {
+ public:
+  StraightLine(uint64_t seed, const GeneratorConfig& cfg, const LowerOptions& o) : p1(o), rng_(Rng::from_seed(seed)), cfg_(cfg) {
+    p1.stream_ids_are_positions();
+  }
+  Pass1 p1;
+
+  // Generator::generate (generator.rs:142-164)
+  void run() {
+    const size_t n = rng_.rand(cfg_.min_instructions, cfg_.max_instructions);
+    const size_t expect = n + cfg_.forced_inputs + 16;
+    p1.reserve_for(expect);
+    is_array_.reserve(expect);
+    len_.reserve(expect);
+    role_.reserve(expect);
+    mask_.reserve(expect);
+    for (uint32_t k = 0; k < cfg_.forced_inputs; k++) {  // extension: scalar input signals declared before anything else
+      skip_name();
+      const size_t pos = add_var(false, 0, kInput);
+      p1.stream_declare(pos, nullptr);
+    }
+    for (size_t i = 0; i < n; i++)
+      if (generate_instr()) n_instr_ = 0;
+    p1.finish();
+  }
+
+ private:
+  enum Role : uint8_t { kLocal, kInput, kOutput };
+
+  void skip_name() { rng_.skip(cfg_.name_len); }  // rand_string: one draw per character (rng.rs:36-45), the name is not kept
+
+  // ScopeStack::add_var + refresh (generator.cpp), for the one scope a straight-line circuit has: position == id
+  size_t add_var(bool is_array, size_t len, Role role) {
+    const size_t pos = is_array_.size();
+    const bool readable = cfg_.inputs_readable && role == kInput;
+    is_array_.push_back(is_array);
+    len_.push_back((uint32_t)len);
+    role_.push_back(role);
+    mask_.push_back(0);
+    ready_fields_.resize(pos + 1);
+    if (role == kLocal) {
+      n_local_++;
+      (is_array ? local_arrays_ : local_fields_).push_back((uint32_t)pos);
+    }
+    if (readable) {
+      if (is_array) {  // every element readable from the start: the array counts as written
+        mask_[pos] = len >= 64 ? ~0ull : ((1ull << len) - 1);
+        touched_list_.push_back((uint32_t)pos);  // positions only grow: the list stays ascending
+      } else {
+        ready_fields_.set(pos, true);
+        ready_signals_.push_back((uint32_t)pos);
+      }
+    }
+    const VariableRole r = role == kLocal ? VariableRole::Local() : VariableRole::Signal(role == kInput ? SignalType::Input : SignalType::Output);
+    p1.add_variable(pos, r, is_array, len, nullptr);
+    return pos;
+  }
+
+  // Generator::generate_instr (generator.rs:166-208): the candidates a straight-line, quadratic-aware configuration has
+  bool generate_instr() {
+    if (n_instr_ >= cfg_.statement_budget) return false;
+    n_instr_ += 1;
+    enum Cand { kVarDecl, kAssign, kArrayAssign, kConstraint };
+    Cand funcs[4];
+    size_t n = 0;
+    funcs[n++] = kVarDecl;
+    if (n_local_ > 0) funcs[n++] = kAssign;
+    if (!local_arrays_.empty()) funcs[n++] = kArrayAssign;
+    funcs[n++] = kConstraint;
+    arena_.reset();
+    switch (funcs[rng_.rand(0, n - 1)]) {
+      case kVarDecl: return gen_var_decl_default();
+      case kAssign: return gen_assign();
+      case kArrayAssign: return gen_array_assign();
+      case kConstraint: return gen_constraint_quadratic();
+    }
+    return false;
+  }
+
+  // Generator::gen_var_decl with nothing given (generator.rs:214-267)
+  bool gen_var_decl_default() {
+    bool is_array = false;
+    size_t len = 0;
+    if (rng_.rand(0, 1) != 0) {
+      is_array = true;
+      len = rng_.rand(1, cfg_.max_array_len);
+    }
+    const Expr* def = nullptr;
+    if (!is_array && rng_.rand(1, 10) != 1) def = generate_expr();
+    Role role = kLocal;
+    if (!def && rng_.rand(0, 1) == 0) {
+      role = rng_.rand(0, 1) == 0 ? kInput : kOutput;
+      if (role == kOutput) role = kLocal;                        // quadratic-aware: every constraint declares its own output
+      if (cfg_.forced_inputs && role == kInput) role = kLocal;   // a fixed set of up-front inputs
+    }
+    skip_name();
+    const size_t pos = add_var(is_array, len, role);
+    p1.stream_declare(pos, def);
+    return true;
+  }
+
+  // generator.rs:269-289
+  bool gen_assign() {
+    if (local_fields_.empty()) return false;
+    const size_t pos = local_fields_[rng_.rand(0, local_fields_.size() - 1)];
+    const Expr* e = generate_expr();
+    ready_fields_.set(pos, true);  // mark_initialized
+    p1.stream_assign(pos, *e);
+    return true;
+  }
+
+  // generator.rs:291-327
+  bool gen_array_assign() {
+    const size_t pos = local_arrays_[rng_.rand(0, local_arrays_.size() - 1)];
+    const size_t n = len_[pos];
+    const Expr* e = generate_expr();
+    const size_t idx = rng_.rand(0, n - 1);
+    if (mask_[pos] == 0)  // first write to this array: the list of written arrays stays ascending
+      touched_list_.insert(std::upper_bound(touched_list_.begin(), touched_list_.end(), (uint32_t)pos), (uint32_t)pos);
+    mask_[pos] |= 1ull << idx;
+    const Expr index = Expr::Constant((uint64_t)idx);
+    p1.stream_array_assign(pos, index, *e);
+    return true;
+  }
+
+  // Generator::generate_expr at depth 0 with the depth limit 1 (generator.rs:484-543): a constant, an operator over
+  // two constants, a variable, an array element
+  const Expr* generate_expr() {
+    const bool has_field_vars = ready_fields_.count() > 0;
+    const bool has_array_vars = !touched_list_.empty();
+    static const ExprKind kArith[] = {ExprKind::Constant, ExprKind::Add, ExprKind::Sub, ExprKind::Mul};
+    const size_t n_fixed = 4;
+    const size_t idx = rng_.rand(0, n_fixed + (has_field_vars ? 1 : 0) + (has_array_vars ? 1 : 0) - 1);
+    if (idx == 0) return arena_.make(Expr::Constant(rng_.next()));
+    if (idx < n_fixed) {
+      const Expr l = Expr::Constant(rng_.next());
+      const Expr r = Expr::Constant(rng_.next());
+      return arena_.make(Expr::Binary(arena_, kArith[idx], l, r));
+    }
+    if (has_field_vars && idx == n_fixed) {  // gen_var_ref (generator.rs:545-566)
+      VarRef v;
+      v.id = ready_fields_.select(rng_.rand(0, ready_fields_.count() - 1));
+      return arena_.make(Expr::Var(v));
+    }
+    return gen_array_index();
+  }
+
+  // generator.rs:572-601: one draw per written array, one more to choose among them
+  const Expr* gen_array_index() {
+    const size_t n = touched_list_.size();
+    const Rng before = rng_;
+    rng_.skip(n);
+    const size_t pick = rng_.rand(0, n - 1);
+    const size_t pos = touched_list_[pick];
+    const size_t written = (size_t)__builtin_popcountll(mask_[pos]);
+    size_t idx = before.peek(pick) % ((uint64_t)written + 1);
+    if (cfg_.safe_array_index) {  // extension: always a written element
+      size_t want = idx % written;
+      uint64_t m = mask_[pos];
+      while (want--) m &= m - 1;
+      idx = (size_t)__builtin_ctzll(m);
+    }
+    VarRef r;
+    r.id = pos;
+    r.idx = idx;
+    return arena_.make(Expr::Var(r));
+  }
+
+  // Generator::gen_linear (extension)
+  Expr gen_linear(bool factor) {
+    const std::vector<uint32_t>& sigs = ready_signals_;
+    const bool always_signal = factor && cfg_.signal_factors;
+    auto term = [&]() -> Expr {
+      if (!sigs.empty() && (always_signal || rng_.rand(0, 3) != 0)) {
+        size_t k = rng_.rand(0, sigs.size() - 1);
+        const size_t keep = (size_t)cfg_.forced_inputs + cfg_.signal_window;
+        if (cfg_.signal_window && sigs.size() > keep && k >= cfg_.forced_inputs && k < sigs.size() - cfg_.signal_window)
+          k = (k % keep < cfg_.forced_inputs) ? k % keep : sigs.size() - keep + k % keep;
+        VarRef v;
+        v.id = sigs[k];
+        return Expr::Var(v);
+      }
+      return Expr::Constant(rng_.next());
+    };
+    const Expr t = term();
+    if (cfg_.max_linear_terms == 1) return t;
+    const uint64_t shape = rng_.rand(0, 2);
+    if (shape == 0) return t;
+    const Expr u = term();
+    return Expr::Binary(arena_, shape == 1 ? ExprKind::Add : ExprKind::Sub, t, u);
+  }
+
+  // Generator::gen_constraint_quadratic (extension): `fresh output <== lin * lin + lin`
+  bool gen_constraint_quadratic() {
+    const Expr a = gen_linear(true);
+    const Expr b = gen_linear(true);
+    const Expr c = gen_linear(false);
+    skip_name();
+    const size_t pos = add_var(false, 0, kOutput);
+    // mark_initialized: an output field is readable from here on, by expressions and by linear parts
+    ready_fields_.set(pos, true);
+    if (!ready_signals_.empty() && ready_signals_.back() >= pos) throw LowerError(ZKIR_LOWER_BAD_AST, "internal: signal order");
+    ready_signals_.push_back((uint32_t)pos);
+    const Expr prod = Expr::Binary(arena_, ExprKind::Mul, a, b);
+    const Expr rhs = Expr::Binary(arena_, ExprKind::Add, prod, c);
+    p1.stream_declare(pos, nullptr);
+    p1.stream_constrain(pos, rhs);
+    return true;
+  }
+
+  Rng rng_;
+  GeneratorConfig cfg_;
+  Arena arena_;  // the expression nodes of the statement in the making
+  size_t n_instr_ = 0;
+  std::vector<uint8_t> is_array_, role_;
+  std::vector<uint32_t> len_;
+  std::vector<uint64_t> mask_;           // arrays: which elements are written (at most 64 elements)
+  std::vector<uint32_t> local_fields_, local_arrays_;  // positions, ascending
+  size_t n_local_ = 0;
+  OrderedSet ready_fields_;              // Field and initialised (gen_var_ref)
+  std::vector<uint32_t> touched_list_;   // arrays with a written element, ascending (gen_array_index)
+  std::vector<uint32_t> ready_signals_;  // signal, Field, initialised, ascending: signals become readable in declaration order (gen_linear)
+};
+
+}  // namespace
+
+bool can_lower_generated(const GeneratorConfig& cfg, const LowerOptions& opts) {
+  return cfg.no_loops && !cfg.enable_if && cfg.max_expr_depth == 1 && cfg.quadratic_aware && cfg.arithmetic_only &&
+         cfg.max_array_len <= 64 && opts.fold_constants;
+}
+
+Tape lower_generated(uint64_t seed, const GeneratorConfig& cfg, const LowerOptions& opts, double* pass1_seconds) {
+  if (!can_lower_generated(cfg, opts)) throw std::invalid_argument("configuration needs the circuit built first");
+  validate_generator_config(cfg);
+  check_options(opts);
+  const auto t0 = std::chrono::steady_clock::now();
+  StraightLine g(seed, cfg, opts);
+  g.run();
+  if (pass1_seconds) *pass1_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return place_tape(g.p1, opts);
+}
+
+Tape Lowerer::lower() {
+  check_options(opts_);
+  Pass1 p1(opts_);
+  p1.run(circuit);
+  return place_tape(p1, opts_);
 }
 
 }  // namespace zkir

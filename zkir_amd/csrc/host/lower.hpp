@@ -43,6 +43,13 @@ class Lowerer {
   LowerOptions opts_;
 };
 
+// Generator(Rng::from_seed(seed), cfg).generate() followed by Lowerer(circuit, opts).lower() without the circuit in
+// between, for the configurations where that is possible (can_lower_generated: straight-line, quadratic-aware
+// campaign circuits): same random draws, same tape, same refusals.  pass1_seconds (nullable) receives the time up
+// to the single-assignment ops (drawing the circuit and pass 1); the rest of the call is slot placement.
+bool can_lower_generated(const zkir_generator_config& cfg, const LowerOptions& opts);
+Tape lower_generated(uint64_t seed, const zkir_generator_config& cfg, const LowerOptions& opts, double* pass1_seconds = nullptr);
+
 }  // namespace zkir
 
 struct zkir_tape {
