@@ -150,8 +150,9 @@ def main():
     ap.add_argument("--log2-vectors", type=int, default=LOG2_VECTORS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (no \"also\" entries)")
-    ap.add_argument("--campaign-circuits", type=int, default=4096,
-                    help="circuits of the configuration-4 sample under \"also\" (the whole job's, shared i mod N)")
+    ap.add_argument("--campaign-circuits", type=int, default=-1,
+                    help="circuits of the configuration-4 sample under \"also\" (the whole job's, shared i mod N); by default "
+                         "12 500 per GPU, which at 8 GPUs is the configuration's 100 000")
     ap.add_argument("--no-outputs", action="store_true",
                     help="config2 only: do not ask for the outputs (witness and checks only): a measurement aid")
     ap.add_argument("--workload", default="config2", choices=["config2", "gadget"],
@@ -330,9 +331,9 @@ def main():
             also.append(entry("configuration 5: Poseidon-style gadget chain (width 4, %d rounds, %d constraints) x 2^16 "
                               "vectors split over the GPUs; witness + checks" % (g_rounds, gt.hdr.n_constraints),
                               gt, mm, n5, k5, "strong"))
-        if args.campaign_circuits > 0:
+        if args.campaign_circuits != 0:
             from zkir_amd import campaign
-            n_circ, n_vec = (64 if dry else args.campaign_circuits), (16 if dry else 1024)
+            n_circ, n_vec = (64 if dry else args.campaign_circuits if args.campaign_circuits > 0 else 12500 * world), (16 if dry else 1024)
             ids = campaign.shard(n_circ, rank, world)
             # the ranks of this job share one host (one node): every rank takes its share of the host's threads
             workers = max(1, min(8, host_threads() // max(1, world)))
@@ -344,7 +345,9 @@ def main():
             host_stats = {}
             fence()
             t0 = time.perf_counter()
-            res_c = campaign.run_local(ids, 7, n_vec, evaluator, group=2048,
+            # a launch per batch the host hands over: the GPU has time to spare, and what is left to evaluate when the
+            # host has finished is one small launch
+            res_c = campaign.run_local(ids, 7, n_vec, evaluator, group=int(os.environ.get("ZKIR_CAMPAIGN_GROUP", "512")),
                                        lowered=campaign.lower_parallel(ids, 7, workers=workers, stats=host_stats))
             t_red = time.perf_counter()
             tot = campaign.reduce_results(res_c, dist if world > 1 else None, device if not rehearse else None)

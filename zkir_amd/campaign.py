@@ -47,6 +47,21 @@ def campaign_config(circuit_id, min_constraints=64, max_constraints=4096):
     return g
 
 
+def campaign_lower_options():
+    """How a campaign lowers: it is bound by the host side (a circuit costs 0.6 to 0.8 ms of one host thread to draw and
+    lower, and 0.03 ms of the GPU to evaluate), so lower skips what only shortens the evaluation: the search for the
+    statement order with the least device-memory traffic (2 ms per circuit), the choice of op order within a statement
+    and the window run as a cache (0.08 ms each; measured on the GPU box's host: 0.755 -> 0.595 ms per circuit and thread
+    without the two).  ZKIR_CAMPAIGN_LOWER="order_ops=1,window_cache=1" in the environment sets options for a measurement."""
+    import os
+    o = api.default_lower_options()
+    o.reorder = o.order_ops = o.window_cache = 0
+    for item in filter(None, os.environ.get("ZKIR_CAMPAIGN_LOWER", "").split(",")):
+        k, v = item.split("=")
+        setattr(o, k.strip(), int(v))
+    return o
+
+
 def lower_parallel(circuit_ids, base_seed, workers=8, window=64, lower_options=None, config_of=campaign_config, stats=None):
     """Generate and lower campaign circuits on `workers` host threads; yields
     (circuit id, class, Tape or None) in id order.  The circuits go to the library `window` x workers
@@ -60,10 +75,7 @@ def lower_parallel(circuit_ids, base_seed, workers=8, window=64, lower_options=N
     import threading
     import time
     if lower_options is None:
-        # a campaign is bound by the host side (generate + lower cost a few ms per circuit, its evaluation some tens of
-        # microseconds), so lower skips the search for the statement order with the least device-memory traffic
-        lower_options = api.default_lower_options()
-        lower_options.reorder = 0
+        lower_options = campaign_lower_options()
     ids = list(circuit_ids)
     step = max(1, window * workers)
     batches = queue.Queue(maxsize=2)

@@ -102,7 +102,33 @@ class Pass1 {
   explicit Pass1(const LowerOptions& o) : opts_(o) {
     max_ops_ = o.max_ops ? o.max_ops : (1u << 22);
     max_iterations_ = o.max_iterations ? o.max_iterations : (1u << 20);
+    // the arrays of the last circuit this thread lowered, emptied: their memory is mapped and warm
+    Storage& st = storage();
+    ops.swap(st.ops);
+    stmt_begin.swap(st.stmt_begin);
+    consts.swap(st.consts);
+    cells_.swap(st.cells);
+    vals_.swap(st.vals);
+    const_table_.swap(st.const_table);
+    ops.clear();
+    stmt_begin.clear();
+    consts.clear();
+    cells_.clear();
+    vals_.clear();
+    const_table_.clear();
   }
+  ~Pass1() {
+    Storage& st = storage();
+    if (ops.capacity() > (1u << 22)) return;  // a giant circuit's arrays are not kept
+    ops.swap(st.ops);
+    stmt_begin.swap(st.stmt_begin);
+    consts.swap(st.consts);
+    cells_.swap(st.cells);
+    vals_.swap(st.vals);
+    const_table_.swap(st.const_table);
+  }
+  Pass1(const Pass1&) = delete;
+  Pass1& operator=(const Pass1&) = delete;
 
   std::vector<SOp> ops;
   std::vector<uint32_t> stmt_begin;  // first op of every executed statement that is not a block (its ops stay together when the tape is reordered)
@@ -216,6 +242,8 @@ class Pass1 {
   }
   void grow_const_table() {
     size_t cap = std::max<size_t>(64, const_table_.size() * 2);
+    if (const_table_.empty())  // the table of the circuit before (memory kept): start at half its size, not from 64 again
+      while (cap * 4 <= const_table_.capacity()) cap *= 2;
     while (cap < (consts.size() + 1) * 2) cap *= 2;
     const_table_.assign(cap, UINT32_MAX);
     for (uint32_t e = 0; e < consts.size(); e++) {
@@ -338,12 +366,6 @@ class Pass1 {
     return r;
   }
 
-  // the linear part of a value of degree <= 1, as terms
-  std::vector<Term> as_terms(Val& v) {
-    if (v.known && v.value.is_zero()) return {};
-    return {Term{U256::from_u64(1), ref_of(v)}};
-  }
-
   // degree bookkeeping: circom accepts `<==` only when the right-hand side can be
   // written A*B + C with A, B, C of degree <= 1 in the signals
   void combine(ExprKind k, Val& a, Val& b, Val* r) {
@@ -356,17 +378,25 @@ class Pass1 {
         Val& q = da == kQuadratic ? a : b;
         Val& l = da == kQuadratic ? b : a;
         r->deg = kQuadratic;
-        Quad nq = quads_[(size_t)q.quad];
-        std::vector<Term> lt = as_terms(l);
+        // the linear operand as at most one term (one allocation for the new term list, none for the operand)
+        const bool has_term = !(l.known && l.value.is_zero());
+        Term lt{U256::from_u64(1), has_term ? ref_of(l) : kNoRef};
+        const Quad& old = quads_[(size_t)q.quad];  // (ref_of above may add a constant, never a quad)
+        Quad nq;
+        nq.qa = old.qa;
+        nq.qb = old.qb;
+        nq.scale = old.scale;
+        nq.terms.reserve(old.terms.size() + 1);
+        nq.terms = old.terms;
         if (k == ExprKind::Sub) {
           if (&q == &b) {  // l - q: negate the quadratic part
             nq.scale = fr::neg(nq.scale);
             for (Term& t : nq.terms) t.coef = fr::neg(t.coef);
           } else {  // q - l
-            for (Term& t : lt) t.coef = fr::neg(t.coef);
+            lt.coef = fr::neg(lt.coef);
           }
         }
-        nq.terms.insert(nq.terms.end(), lt.begin(), lt.end());
+        if (has_term) nq.terms.push_back(lt);
         r->quad = (int32_t)quads_.size();
         quads_.push_back(std::move(nq));
       }
@@ -535,7 +565,7 @@ class Pass1 {
     output_written_[out_index] = true;
     const Ref one = const_of(U256::from_u64(1));
     if (v.deg == kQuadratic) {
-      const Quad Q = quads_[(size_t)v.quad];  // (a copy: the ops emitted below do not touch quads_, but cheap enough to not depend on it)
+      const Quad& Q = quads_[(size_t)v.quad];  // (the ops emitted below add values and constants, never a quad: the reference stays good)
       Ref A = Q.qa;
       if (!(Q.scale == U256::from_u64(1))) A = new_value(ZKIR_OP_MUL, const_of(Q.scale), A);
       const Ref lin = materialize_terms(Q.terms);
@@ -604,6 +634,17 @@ class Pass1 {
     if (++iterations_ > max_iterations_) fail(ZKIR_LOWER_LOOP_CAP, "loop trip cap exceeded");
   }
 
+  struct Storage {
+    std::vector<SOp> ops;
+    std::vector<uint32_t> stmt_begin, const_table;
+    std::vector<U256> consts;
+    std::vector<Cells> cells;
+    std::vector<Val> vals;
+  };
+  static Storage& storage() {
+    static thread_local Storage st;
+    return st;
+  }
   LowerOptions opts_;
   bool ids_are_positions_ = false;
   size_t max_ops_;
@@ -650,8 +691,16 @@ StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>&
 
   // last op that reads each value, and whether every read can come from the accumulator:
   // the accumulator holds value v from its defining op until the next defining op has run
-  std::vector<int64_t> def_at(nv, -1), last_use(nv, -1);
-  std::vector<int64_t> next_def(n + 1, (int64_t)n);  // index of the first defining op at or after i
+  static thread_local struct {  // (memory kept from call to call, per thread: fresh arrays per circuit are mostly page faults)
+    std::vector<int64_t> def_at, last_use, next_def;
+    std::vector<Home> home;
+    std::vector<int32_t> dies_head, dies_next;
+  } W;
+  std::vector<int64_t>&def_at = W.def_at, &last_use = W.last_use;
+  def_at.assign(nv, -1);
+  last_use.assign(nv, -1);
+  std::vector<int64_t>& next_def = W.next_def;  // index of the first defining op at or after i
+  next_def.assign(n + 1, (int64_t)n);
   for (int64_t i = (int64_t)n - 1; i >= 0; i--) next_def[i] = defines(op_at(i)) ? i : next_def[i + 1];
   auto note_use = [&](Ref r, int64_t at) {
     if (r >= 0) last_use[r] = std::max(last_use[r], at);
@@ -669,11 +718,14 @@ StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>&
     if (defines(o)) def_at[o.dst] = (int64_t)i;
   }
 
-  std::vector<Home> home(nv);
+  std::vector<Home>& home = W.home;
+  home.assign(nv, Home());
   std::vector<uint32_t> free_l, free_g;
   for (uint32_t k = opts.n_lslots; k-- > 0;) free_l.push_back(k);
   // values whose slot is released after op i
-  std::vector<int32_t> dies_head(n, -1), dies_next(nv, -1);  // per op: list of the values whose last read it is
+  std::vector<int32_t>&dies_head = W.dies_head, &dies_next = W.dies_next;  // per op: list of the values whose last read it is
+  dies_head.assign(n, -1);
+  dies_next.assign(nv, -1);
   const int64_t kWindowLifetime = opts.window_lifetime ? opts.window_lifetime : 48;
 
   StreamOut out;
@@ -1645,17 +1697,17 @@ Placement place_strands(const std::vector<SOp>& ops, int32_t nv) {
 
 void write_tape(Tape& tape, const Pass1& p1, const std::vector<zkir_op>& out_ops, const std::vector<uint32_t>& triples) {
   const size_t n = out_ops.size();
-  tape.blob.resize(n * sizeof(zkir_op) + p1.consts.size() * 32 + triples.size() * 4);
-  uint8_t* w = tape.blob.data();
-  if (n) std::memcpy(w, out_ops.data(), n * sizeof(zkir_op));
-  w += n * sizeof(zkir_op);
+  tape.blob.clear();
+  tape.blob.reserve(n * sizeof(zkir_op) + p1.consts.size() * 32 + triples.size() * 4);  // (appended to, not zero-filled first)
+  const uint8_t* ob = (const uint8_t*)out_ops.data();
+  tape.blob.insert(tape.blob.end(), ob, ob + n * sizeof(zkir_op));
   for (const U256& c : p1.consts) {
     uint32_t l[8];
     c.limbs32(l);
-    std::memcpy(w, l, 32);
-    w += 32;
+    tape.blob.insert(tape.blob.end(), (const uint8_t*)l, (const uint8_t*)l + 32);
   }
-  if (!triples.empty()) std::memcpy(w, triples.data(), triples.size() * 4);
+  const uint8_t* tb = (const uint8_t*)triples.data();
+  tape.blob.insert(tape.blob.end(), tb, tb + triples.size() * 4);
   tape.inputs = p1.inputs;
   tape.outputs = p1.outputs;
 }
@@ -1832,7 +1884,8 @@ Tape place_tape(Pass1& p1, const LowerOptions& opts_) {
     if (k) stream = schedule_statements(ops, p1.stmt_begin, nv, lookaheads[k]);
     StreamOut cand = opts_.window_cache ? place_stream_cached(ops, stream, nv, check_id, reorder, opts_, &triples)
                                         : place_stream(ops, stream, nv, {}, check_id, reorder, opts_, &triples);
-    const uint64_t cost = device_slot_traffic(cand.ops, one_word) * 4096ull + std::min<uint32_t>(cand.n_g, 4095u);
+    // (with one candidate there is nothing to compare: its traffic is not modelled)
+    const uint64_t cost = !reorder ? 0 : device_slot_traffic(cand.ops, one_word) * 4096ull + std::min<uint32_t>(cand.n_g, 4095u);
     if (cost < best_cost) {
       best_cost = cost;
       so = std::move(cand);
@@ -2012,7 +2065,7 @@ class StraightLine {
   // generator.rs:572-601: one draw per written array, one more to choose among them
   const Expr* gen_array_index() {
     const size_t n = touched_list_.size();
-    const Rng before = rng_;
+    Rng before = rng_;
     rng_.skip(n);
     const size_t pick = rng_.rand(0, n - 1);
     const size_t pos = touched_list_[pick];

@@ -31,7 +31,7 @@ class Rng {
   // per written array before it uses one of the draws (generator.rs:572-601): hundreds of calls whose values
   // nobody reads.
   static uint64_t advanced(uint64_t s, uint64_t n) {
-    if (n < 24) {
+    if (n < 64) {  // (a step is three shifts and three xors; the tables only pay once their cache misses do)
       for (; n; n--) s = step(s);
       return s;
     }
