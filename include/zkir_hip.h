@@ -120,6 +120,14 @@ typedef enum zkir_opcode {
   ZKIR_OP_BNOT = 5,    /* ~a over 254 bits, then mod p   (circom.rs:136)                */
   ZKIR_OP_BNOT256 = 6, /* ~a over 256 bits, then mod p   (alternative reading of `~`)   */
   ZKIR_OP_BARRIER = 7, /* strand tapes: wait for the other strands (no operands)        */
+  /* Scaled values.  lower may keep a value v of the circuit as the tape value v * 2^-256 mod p ("scaled"): the
+     product of a scaled and a plain value is scaled, sums of scaled values are scaled, and the two ops below take
+     scaled values in and out of a tape at no cost on the device, which holds a tape value x as the words of
+     x * 2^256 mod p: the words of a scaled value are those of the circuit's value itself.  A circuit whose every
+     signal is an output then pays no conversion per output, only a product by the constant 2^256 for the signals
+     that are needed as the plain factor of a product.  To an interpreter of tapes these are just two more ops.  */
+  ZKIR_OP_INPUT_SCALED = 8,  /* dst = inputs[a] * 2^-256 mod p                          */
+  ZKIR_OP_OUTPUT_SCALED = 9, /* outputs[dst] = a * 2^256 mod p                          */
   /* binary */
   ZKIR_OP_ADD = 16,  /* circom.rs:35-41   */
   ZKIR_OP_SUB = 17,  /* circom.rs:42-46   */
@@ -164,7 +172,9 @@ typedef struct zkir_tape_hdr {
   uint32_t strand_ops[8]; /* strand tapes: ops of each strand (sum = n_ops); else 0 */
   uint32_t n_xslots;      /* strand tapes: exchange slots (<= ZKIR_MAX_XSLOTS)  */
   uint32_t n_strands;     /* strand tapes: ZKIR_STRANDS or ZKIR_MAX_STRANDS; else 0 */
-  uint32_t reserved;      /* 0 */
+  uint32_t n_scale_ops;   /* of the ZKIR_OP_MUL ops, those lower added to move a value between its scaled and its
+                             plain form (products by the constants 2^256 or 2^-256): not the circuit's own
+                             multiplications (work accounting only, like n_mul_ops)  */
 } zkir_tape_hdr; /* 88 bytes; n_gslots / n_lslots of a strand tape are per strand */
 
 #define ZKIR_MAX_LSLOTS 16u
@@ -312,6 +322,10 @@ typedef struct zkir_lower_options {
   uint32_t order_ops;      /* 1: the ops of one statement run in the order that keeps
                               the fewest temporaries alive (`A*B + C`: C first, so the
                               product is forwarded into the sum); 0: as written  */
+  uint32_t scaled_values;  /* 1: tapes made of + - * may keep values scaled by 2^-256
+                              (ZKIR_OP_INPUT_SCALED / ZKIR_OP_OUTPUT_SCALED) where that
+                              saves more output conversions than it adds products;
+                              0: every value plain                              */
 } zkir_lower_options;
 
 int32_t zkir_lower_options_default(zkir_lower_options* o);

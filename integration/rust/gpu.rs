@@ -18,7 +18,7 @@ use std::os::raw::c_char;
 pub struct TapeHdr {
     pub magic: u32, pub version: u32, pub n_inputs: u32, pub n_outputs: u32, pub n_consts: u32,
     pub n_ops: u32, pub n_gslots: u32, pub n_lslots: u32, pub n_constraints: u32, pub n_mul_ops: u32,
-    pub flags: u32, pub strand_ops: [u32; 8], pub n_xslots: u32, pub n_strands: u32, pub reserved: u32,
+    pub flags: u32, pub strand_ops: [u32; 8], pub n_xslots: u32, pub n_strands: u32, pub n_scale_ops: u32,
 }
 
 /// zkir_lower_options of the header; `LowerOptions::default()` is NOT the library's default:
@@ -30,7 +30,7 @@ pub struct TapeHdr {
 pub struct LowerOptions {
     pub fold_constants: u32, pub n_lslots: u32, pub reuse_slots: u32, pub max_ops: u32, pub bnot_variant: u32,
     pub use_acc: u32, pub max_iterations: u32, pub window_lifetime: u32, pub strands: u32, pub max_xslots: u32,
-    pub reorder: u32, pub window_cache: u32, pub order_ops: u32,
+    pub reorder: u32, pub window_cache: u32, pub order_ops: u32, pub scaled_values: u32,
 }
 
 #[link(name = "zkir_hip")]

@@ -27,12 +27,13 @@ typedef struct { uint64_t w[4]; } fe;
 typedef struct { uint32_t code, dst, a, b; } op_t;
 typedef struct {
   uint32_t magic, version, n_inputs, n_outputs, n_consts, n_ops, n_gslots, n_lslots, n_constraints, n_mul_ops, flags,
-      strand_ops[8], n_xslots, n_strands, reserved;
+      strand_ops[8], n_xslots, n_strands, n_scale_ops;
 } hdr_t;
 enum { K_GSLOT = 0, K_LSLOT = 1, K_CONST = 2, K_INPUT = 3, K_ACC = 4, K_NONE = 5, K_XSLOT = 6 };
 enum { F_STRANDS = 1, STRANDS = 8 };  /* STRANDS: the most a tape can have (n_strands is 4 or 8) */
 enum {
   OP_NOP = 0, OP_INPUT = 1, OP_OUTPUT = 2, OP_COPY = 3, OP_NEG = 4, OP_BNOT = 5, OP_BNOT256 = 6, OP_BARRIER = 7,
+  OP_INPUT_SCALED = 8, OP_OUTPUT_SCALED = 9, /* the input times 2^-256, the output times 2^256 (include/zkir_hip.h) */
   OP_ADD = 16, OP_SUB, OP_MUL, OP_POW, OP_DIV, OP_IDIV, OP_REM, OP_LT, OP_LE, OP_GT, OP_GE, OP_EQ, OP_AND, OP_OR,
   OP_BAND, OP_BOR, OP_BXOR, OP_SHR, OP_SHL,
   OP_CHECK = 48
@@ -248,8 +249,15 @@ static void* run_range(void* arg) {
           if (code == OP_BARRIER) { pc++; break; }
           if (code == OP_INPUT) {
             fe v; load_soa(&v, j->in, j->N, op->a & 0x1fffffff, t); to_mont(&acc, &v);
+          } else if (code == OP_INPUT_SCALED) {
+            /* values are held here as x * 2^256 mod p (Montgomery form with the same radix): the tape value
+               input * 2^-256 is held as the input's own words */
+            load_soa(&acc, j->in, j->N, op->a & 0x1fffffff, t);
           } else if (code == OP_OUTPUT) {
             if (j->out) { fe v; f_mul(&v, SRC(op->a), &one); store_soa(j->out, j->N, op->dst, t, &v); }
+            continue;
+          } else if (code == OP_OUTPUT_SCALED) {
+            if (j->out) store_soa(j->out, j->N, op->dst, t, SRC(op->a));  /* (a * 2^256) is what is held */
             continue;
           } else if (code == OP_CHECK) {
             fe v; f_mul(&v, SRC(op->a), SRC(op->b));

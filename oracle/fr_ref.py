@@ -142,6 +142,9 @@ def neg(a):
 
 # opcode numbers of include/zkir_hip.h
 OP_NOP, OP_INPUT, OP_OUTPUT, OP_COPY, OP_NEG, OP_BNOT, OP_BNOT256, OP_BARRIER = 0, 1, 2, 3, 4, 5, 6, 7
+OP_INPUT_SCALED, OP_OUTPUT_SCALED = 8, 9  # the input times 2^-256, the output times 2^256 (include/zkir_hip.h)
+SCALE = pow(2, 256, P)
+SCALE_INV = pow(SCALE, -1, P)
 (OP_ADD, OP_SUB, OP_MUL, OP_POW, OP_DIV, OP_IDIV, OP_REM, OP_LT, OP_LE, OP_GT, OP_GE, OP_EQ, OP_AND, OP_OR,
  OP_BAND, OP_BOR, OP_BXOR, OP_SHR, OP_SHL) = range(16, 35)
 OP_CHECK = 48
@@ -158,7 +161,7 @@ OP_NAMES = {
     OP_BNOT256: "bnot256", OP_ADD: "add", OP_SUB: "sub", OP_MUL: "mul", OP_POW: "pow", OP_DIV: "div",
     OP_IDIV: "idiv", OP_REM: "rem", OP_LT: "lt", OP_LE: "le", OP_GT: "gt", OP_GE: "ge", OP_EQ: "eq",
     OP_AND: "and", OP_OR: "or", OP_BAND: "band", OP_BOR: "bor", OP_BXOR: "bxor", OP_SHR: "shr", OP_SHL: "shl",
-    OP_CHECK: "check",
+    OP_CHECK: "check", OP_INPUT_SCALED: "input_scaled", OP_OUTPUT_SCALED: "output_scaled",
 }
 
 KIND_SHIFT = 29
@@ -226,12 +229,14 @@ def eval_tape_one(ops, consts, inputs, strand_ops=None):
                     if not strand_ops:
                         raise ValueError("BARRIER in a plain tape")
                     break
-                if code == OP_INPUT:
+                if code in (OP_INPUT, OP_INPUT_SCALED):
                     assert a >> KIND_SHIFT == K_INPUT
-                    st["acc"] = inputs[a & INDEX_MASK]
+                    st["acc"] = inputs[a & INDEX_MASK] if code == OP_INPUT else mul(inputs[a & INDEX_MASK], SCALE_INV)
                     wr(st, dst, st["acc"])
                 elif code == OP_OUTPUT:
                     outputs[dst] = rd(st, a)
+                elif code == OP_OUTPUT_SCALED:
+                    outputs[dst] = mul(rd(st, a), SCALE)
                 elif code == OP_CHECK:
                     if mul(rd(st, a), rd(st, b)) != rd(st, dst):
                         unsat.append((full >> 8) - 1 if full >> 8 else k)

@@ -369,11 +369,14 @@ def test_batched_upload_gives_the_same_results(ctx):
     # a bad tape anywhere in the batch: nothing is uploaded
     bad_hdr = api.TapeHdr.from_buffer_copy(bytes(tapes[0].hdr))
     bad_hdr.n_consts += 1  # the blob no longer matches the header
-    class Fake:  # a tape object whose header lies about its blob
-        def __init__(self, t, hdr):
-            self._h, self.hdr = t._h, hdr
     with pytest.raises(z.ZkirError):
-        ctx.upload_many([tapes[1], Fake(tapes[0], bad_hdr)])
+        ctx.upload_many_parts([(tapes[1].hdr, tapes[1].blob()), (bad_hdr, tapes[0].blob())])
+    # the same pairs with honest headers go through the validating entry point and run like the handles did
+    pids = ctx.upload_many_parts([(t.hdr, t.blob()) for t, _ in plain])
+    got2, _ = ctx.eval_multi(pids, np.concatenate(blocks), n)
+    assert got2 == want
+    for tid in pids:
+        ctx.release(tid)
 
 
 def test_campaign_on_one_gpu():

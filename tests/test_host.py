@@ -45,7 +45,7 @@ def test_abi_exports_every_declared_symbol():
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(api.TapeHdr) == 88
     assert ctypes.sizeof(api.GeneratorConfig) == 20 * 4
-    assert ctypes.sizeof(api.LowerOptions) == 13 * 4
+    assert ctypes.sizeof(api.LowerOptions) == 14 * 4
 
 
 def test_default_config_is_the_reference_literals():

@@ -141,11 +141,22 @@ def test_every_operand_kind_and_op():
         (F.OP_CHECK, O(F.K_CONST, 3), O(F.K_LSLOT, 0), O(F.K_LSLOT, 0)),  # fails (almost surely)
         (F.OP_CHECK, O(F.K_GSLOT, 1), O(F.K_GSLOT, 0), O(F.K_CONST, 3)),
         (F.OP_CHECK, O(F.K_CONST, 0), O(F.K_CONST, 0), ACC),            # 0*acc == 0: holds
+        # scaled values: the input times 2^-256 in, times a plain value, plus a scaled one, times 2^256 out
+        (F.OP_INPUT_SCALED, O(F.K_GSLOT, 2), O(F.K_INPUT, 1), NONE),
+        (F.OP_INPUT_SCALED, NONE, O(F.K_INPUT, 0), NONE),
+        (F.OP_MUL, O(F.K_LSLOT, 2), ACC, O(F.K_GSLOT, 0)),
+        (F.OP_ADD, NONE, ACC, O(F.K_GSLOT, 2)),
+        (F.OP_OUTPUT_SCALED, 4, ACC, NONE),
+        (F.OP_OUTPUT_SCALED, 5, O(F.K_GSLOT, 2), NONE),
+        (F.OP_OUTPUT_SCALED, 6, O(F.K_LSLOT, 2), NONE),
+        (F.OP_OUTPUT_SCALED, 7, O(F.K_CONST, 4), NONE),
+        (F.OP_SUB, NONE, ACC, O(F.K_GSLOT, 2)),
+        (F.OP_CHECK, ACC, O(F.K_LSLOT, 2), O(F.K_CONST, 1)),            # (scaled product) * 1 == it: holds
     ]
     inputs = [[rnd.randrange(F.P) for _ in range(3)] for _ in range(70)]
     inputs[0] = [0, F.P - 1, 1]
     inputs[1] = [F.P - 1, F.P - 1, F.P - 1]
-    check_tape(ops, consts, inputs, 4, 4, 4, [(0, 0, 0, True), (1, 0, 1, True), (69, 1, 5, True), (33, 3, 63, True),
+    check_tape(ops, consts, inputs, 8, 4, 4, [(0, 0, 0, True), (1, 0, 1, True), (69, 1, 5, True), (33, 3, 63, True),
                                               (5, 2, 7, False)])
 
 
@@ -194,7 +205,7 @@ def test_generated_circuits(seed, statements, opts):
     tape = _lowered(seed, statements, **opts)
     h = tape.hdr
     ops, consts = tape.ops(), tape.consts()
-    assert all((c & 0xFF) in (0, 1, 2, 3, 4, 16, 17, 18, 48) for c, _, _, _ in ops)
+    assert all((c & 0xFF) in (0, 1, 2, 3, 4, 8, 9, 16, 17, 18, 48) for c, _, _, _ in ops)
     rnd = random.Random(seed)
     n_vec = 300
     inputs = [[rnd.randrange(F.P) for _ in range(h.n_inputs)] for _ in range(n_vec)]

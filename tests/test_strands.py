@@ -105,7 +105,7 @@ def test_validation_of_strand_tapes():
     cases.append(rebuilt(ops, n_xslots=49))
     cases.append(rebuilt(ops, n_strands=5))  # a strand tape has 4 or 8 strands
     cases.append(rebuilt(ops, n_strands=8))  # the fifth to eighth hold no barriers
-    cases.append(rebuilt(ops, reserved=1))
+    cases.append(rebuilt(ops, n_scale_ops=99))  # more scaling products than products
     for h, b in cases:
         with pytest.raises(z.ZkirError):
             z.Tape.from_parts(h, b)
@@ -208,7 +208,7 @@ def test_lowering_into_strands_keeps_every_result(n_strands):
                 + (32 if n_strands == 4 else 48) * 2304 + 16 <= 160 * 1024 and greedy.n_lslots <= (4 if n_strands == 4 else 2)
             if n_strands == 8:  # strands 4..7 hold only what defines nothing
                 tail = ops[sum(list(st.hdr.strand_ops)[:4]):]
-                assert all(o[0] & 0xFF in (F.OP_OUTPUT, F.OP_CHECK, F.OP_BARRIER) for o in tail), name
+                assert all(o[0] & 0xFF in (F.OP_OUTPUT, F.OP_OUTPUT_SCALED, F.OP_CHECK, F.OP_BARRIER) for o in tail), name
             # the Python interpreter agrees on one vector
             o_py, u_py, _ = F.eval_tape_one(ops, st.consts(), vecs[0], strand_ops=list(st.hdr.strand_ops)[:st.hdr.n_strands])
             assert [o_py[k] for k in range(st.hdr.n_outputs)] == z.unpack_outputs(got[0])[0] and u_py == []

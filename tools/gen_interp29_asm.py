@@ -35,6 +35,11 @@ SLOT_BYTES, WAVE_BYTES = 9216, 2304
 Q_CONST = 1354  # floor(2^264 / p): floor(x_8 * Q_CONST / 2^32) is floor(x / p) or one less for x below 4000 p
 P32 = [(fr29.P >> (32 * j)) & 0xFFFFFFFF for j in range(8)]
 R2_29 = fr29.limbs29(fr29.R2)
+# this stream holds a tape value x as x * 2^261 mod p.  The input times 2^-256: the input's words times 2^5, i.e. a product
+# with 2^266 (the product divides by 2^261); the output times 2^256: the held value times 2^256 / 2^261, i.e. a product
+# with the plain integer 2^256
+IN_SCALED_29 = fr29.limbs29(pow(2, 266, fr29.P))
+OUT_SCALED_29 = fr29.limbs29(1 << 256)
 
 
 def dominating_multiple(limb_bound, top_bound):
@@ -99,6 +104,7 @@ assert S_LAST <= 99  # s100 and above are reserved by the compiler on this targe
 
 K_GSLOT, K_LSLOT, K_CONST, K_INPUT, K_ACC, K_NONE, K_XSLOT = 0, 1, 2, 3, 4, 5, 6
 OP_INPUT, OP_OUTPUT, OP_COPY, OP_NEG, OP_BARRIER, OP_ADD, OP_SUB, OP_MUL, OP_CHECK = 1, 2, 3, 4, 7, 16, 17, 18, 48
+OP_INPUT_SCALED, OP_OUTPUT_SCALED = 8, 9  # the input times 2^-256 / the output times 2^256
 
 # operands of the asm statement (all inputs are read-only)
 IN_OPS, IN_NOPS, IN_CST, IN_NCST = "%[ops]", "%[n_ops]", "%[consts]", "%[n_consts]"
@@ -466,7 +472,11 @@ def build():
     a.label(".Lz29_unary")
     a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_OUTPUT))
     a.e("s_cbranch_scc1 .Lz29_output")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_OUTPUT_SCALED))
+    a.e("s_cbranch_scc1 .Lz29_output")
     a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_INPUT))
+    a.e("s_cbranch_scc1 .Lz29_input")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_INPUT_SCALED))
     a.e("s_cbranch_scc1 .Lz29_input")
     a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_COPY))
     a.e("s_cbranch_scc1 .Lz29_copy")
@@ -536,8 +546,15 @@ def build():
     limb_offsets()
     for j in range(8):
         a.e("buffer_load_dword %s, %s, %s, %s offen" % (W8[j], IN_VVEC, D_IO, cst_word(j)))
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_INPUT_SCALED))
+    a.e("s_cbranch_scc1 .Lz29_input_scaled")
     for j in range(9):
         a.e("v_mov_b32 %s, 0x%08x" % (B9[j], R2_29[j]))
+    a.e("s_branch .Lz29_input_mul")
+    a.label(".Lz29_input_scaled")
+    for j in range(9):
+        a.e("v_mov_b32 %s, 0x%08x" % (B9[j], IN_SCALED_29[j]))
+    a.label(".Lz29_input_mul")
     a.e("s_mov_b32 %s, -1" % TAG_A)
     a.e("s_mov_b32 %s, -1" % TAG_B)
     a.e("s_waitcnt vmcnt(0)")
@@ -549,10 +566,26 @@ def build():
     a.e("s_cbranch_scc1 .Lz29_next")
     fetch(a, OP[2], VA, AD_A, acc_label=".Lz29_out_acc", stem="o", tag=TAG_A)
     wait_loads(a)
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_OUTPUT_SCALED))
+    a.e("s_cbranch_scc1 .Lz29_out_scaled")
     redc_stream(a, A9)
     a.e("s_branch .Lz29_out_store")
+    a.label(".Lz29_out_scaled")  # times 2^256 / 2^261: a product with the integer 2^256, below 1.07 p
+    a.e("s_mov_b32 %s, -1" % TAG_B)
+    for j in range(9):
+        a.e("v_mov_b32 %s, 0x%08x" % (B9[j], OUT_SCALED_29[j]))
+    mul_stream(a, A9, B9, M9)
+    a.e("s_branch .Lz29_out_store")
     a.label(".Lz29_out_acc")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_OUTPUT_SCALED))
+    a.e("s_cbranch_scc1 .Lz29_out_acc_scaled")
     redc_stream(a, ACC9)
+    a.e("s_branch .Lz29_out_store")
+    a.label(".Lz29_out_acc_scaled")
+    a.e("s_mov_b32 %s, -1" % TAG_B)
+    for j in range(9):
+        a.e("v_mov_b32 %s, 0x%08x" % (B9[j], OUT_SCALED_29[j]))
+    mul_stream(a, ACC9, B9, M9)
     a.label(".Lz29_out_store")
     # the value is below 1.02 p: pack it to 8 x 32 bits and subtract p once if it is not below p
     fr29.pack29(a.lines, W8, M9, VT0)

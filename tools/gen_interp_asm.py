@@ -104,6 +104,7 @@ assert S_LAST <= 99  # s100 and above are reserved by the compiler on this targe
 
 K_GSLOT, K_LSLOT, K_CONST, K_INPUT, K_ACC, K_NONE, K_XSLOT = 0, 1, 2, 3, 4, 5, 6
 OP_INPUT, OP_OUTPUT, OP_COPY, OP_NEG, OP_BARRIER, OP_ADD, OP_SUB, OP_MUL, OP_CHECK = 1, 2, 3, 4, 7, 16, 17, 18, 48
+OP_INPUT_SCALED, OP_OUTPUT_SCALED = 8, 9  # the input times 2^-256 / the output times 2^256: the held words as they are
 
 # operands of the asm statement (all inputs are read-only)
 IN_OPS, IN_NOPS, IN_CST, IN_NCST = "%[ops]", "%[n_ops]", "%[consts]", "%[n_consts]"
@@ -530,9 +531,13 @@ def build():
 
     # ---- INPUT, OUTPUT, COPY, NEG ------------------------------------------
     a.label(".Lzk_unary")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_OUTPUT_SCALED))
+    a.e("s_cbranch_scc1 .Lzk_output")
     a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_OUTPUT))
     a.e("s_cbranch_scc1 .Lzk_output")
     a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_INPUT))
+    a.e("s_cbranch_scc1 .Lzk_input")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_INPUT_SCALED))
     a.e("s_cbranch_scc1 .Lzk_input")
     a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_COPY))
     a.e("s_cbranch_scc1 .Lzk_copy")
@@ -568,6 +573,8 @@ def build():
     a.e("s_and_b32 %s, %s, 0x1fffffff" % (T1, OP[2]))
     io_descriptor(IN_INB, T1)
     limb_offsets()
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_INPUT_SCALED))
+    a.e("s_cbranch_scc1 .Lzk_input_scaled")
     for j in range(8):
         a.e("buffer_load_dword %s, %s, %s, %s offen" % (A8[j], IN_VVEC, D_IO, cst_word(j)))
     for j in range(8):
@@ -576,16 +583,34 @@ def build():
     a.e("s_mov_b32 %s, -1" % TAG_B)
     a.e("s_waitcnt vmcnt(0)")
     a.e("s_branch .Lzk_mul_ab")
+    # the input times 2^-256 is held as the input's own words: loaded into the accumulator, no product
+    a.label(".Lzk_input_scaled")
+    for j in range(8):
+        a.e("buffer_load_dword %s, %s, %s, %s offen" % (ACC8[j], IN_VVEC, D_IO, cst_word(j)))
+    a.e("s_waitcnt vmcnt(0)")
+    a.e("s_branch .Lzk_store")
 
     a.label(".Lzk_output")
     a.e("s_cmp_eq_u64 %s, 0" % IN_OUTB)  # nobody wants the outputs: skip the conversion too
     a.e("s_cbranch_scc1 .Lzk_next")
     fetch(a, OP[2], VA, AD_A, acc_label=".Lzk_out_acc", stem="o", tag=TAG_A)
     wait_loads(a)
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_OUTPUT_SCALED))
+    a.e("s_cbranch_scc1 .Lzk_out_scaled")
     redc_stream(a, A8)
     a.e("s_branch .Lzk_out_store")
+    a.label(".Lzk_out_scaled")  # the output times 2^256: the held words as they are
+    for j in range(8):
+        a.e("v_mov_b32 %s, %s" % (E(j), A8[j]))
+    a.e("s_branch .Lzk_out_store")
     a.label(".Lzk_out_acc")
+    a.e("s_cmp_eq_u32 %s, %d" % (CODE, OP_OUTPUT_SCALED))
+    a.e("s_cbranch_scc1 .Lzk_out_acc_scaled")
     redc_stream(a, ACC8)
+    a.e("s_branch .Lzk_out_store")
+    a.label(".Lzk_out_acc_scaled")
+    for j in range(8):
+        a.e("v_mov_b32 %s, %s" % (E(j), ACC8[j]))
     a.label(".Lzk_out_store")
     io_descriptor(IN_OUTB, OP[1])
     limb_offsets()

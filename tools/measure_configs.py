@@ -27,18 +27,16 @@ def main():
     # (ZKIR_MEASURE_REORDER=0: program order, as a campaign lowers them)
     options = z.default_lower_options()
     options.reorder = int(os.environ.get("ZKIR_MEASURE_REORDER", "1"))
+    options.scaled_values = int(os.environ.get("ZKIR_MEASURE_SCALED", str(options.scaled_values)))
     tapes = [t for _, cls, t in campaign.lower_parallel(range(n_circuits), 7, workers=16, lower_options=options) if t is not None]
     # longest tapes first: the work queue hands items out in order, so the tail is made of short ones
     tapes.sort(key=lambda t: -t.hdr.n_ops)
     host_s = time.time() - t0
     tids = [ctx.upload(t) for t in tapes]
     words = sum(t.hdr.n_inputs for t in tapes) * 8 * n_vec
-    inp = torch.randint(0, 1 << 32, (words,), dtype=torch.int64, device=dev).to(torch.int32)
-    off = 0
-    for t in tapes:
-        blk = inp[off:off + t.hdr.n_inputs * 8 * n_vec].view(t.hdr.n_inputs, 8, n_vec)
-        blk[:, 7, :] &= 0x0FFFFFFF
-        off += t.hdr.n_inputs * 8 * n_vec
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    inp = campaign.uniform_inputs(torch, max(1, words // (8 * n_vec)), n_vec, dev, gen).view(-1)  # uniform in [0, p)
     unsat = torch.zeros(len(tapes), dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     group = int(os.environ.get('ZKIR_GROUP', len(tids)))
@@ -57,7 +55,8 @@ def main():
     print(json.dumps({"config": "3: %d distinct circuits (%d lowered OK, %d..%d constraints) x %d vectors" % (
         n_circuits, len(tapes), min(t.hdr.n_constraints for t in tapes), max(t.hdr.n_constraints for t in tapes), n_vec),
         "gpu_ms": 1e3 * dt, "checks_per_s": checks / dt, "fr_mul_per_s": muls / dt, "unsat": int(unsat.sum()),
-        "host_generate_lower_s_16_threads": host_s, "reorder": options.reorder,
+        "host_generate_lower_s_16_threads": host_s, "reorder": options.reorder, "scaled_values": options.scaled_values,
+        "scaling_products": sum(t.hdr.n_scale_ops for t in tapes),
         "mulhi_frac": 128.0 * muls / dt / ctx.int_mul_rate(0)}))
 
 

@@ -37,7 +37,7 @@ class LowerRejected(ZkirError):
 class TapeHdr(ctypes.Structure):
     _fields_ = [(n, c_uint32) for n in ("magic", "version", "n_inputs", "n_outputs", "n_consts", "n_ops", "n_gslots",
                                         "n_lslots", "n_constraints", "n_mul_ops", "flags")] + [("strand_ops", c_uint32 * 8), ("n_xslots", c_uint32), ("n_strands", c_uint32),
-                                                                                                ("reserved", c_uint32)]
+                                                                                                ("n_scale_ops", c_uint32)]
 
 
 class GeneratorConfig(ctypes.Structure):
@@ -50,7 +50,7 @@ class GeneratorConfig(ctypes.Structure):
 
 class LowerOptions(ctypes.Structure):
     _fields_ = [(n, c_uint32) for n in ("fold_constants", "n_lslots", "reuse_slots", "max_ops", "bnot_variant",
-                                        "use_acc", "max_iterations", "window_lifetime", "strands", "max_xslots", "reorder", "window_cache", "order_ops")]
+                                        "use_acc", "max_iterations", "window_lifetime", "strands", "max_xslots", "reorder", "window_cache", "order_ops", "scaled_values")]
 
 
 def _load():
@@ -369,6 +369,20 @@ class Context:
         self._check(lib.zkir_tape_upload_handles(self._h, n, handles, ids))
         for k, t in enumerate(tapes):
             self._tapes[ids[k]] = (t.hdr.n_inputs, t.hdr.n_outputs)
+        return list(ids)
+
+    def upload_many_parts(self, parts):
+        """zkir_tape_upload_many for (header, blob bytes) pairs from anywhere: every op is validated before
+        anything is uploaded."""
+        n = len(parts)
+        hdrs = (TapeHdr * n)(*[h for h, _ in parts])
+        keep = [ctypes.create_string_buffer(b, len(b)) for _, b in parts]
+        blobs = (c_void_p * n)(*[ctypes.addressof(k) for k in keep])
+        sizes = (c_size_t * n)(*[len(b) for _, b in parts])
+        ids = (c_uint32 * n)()
+        self._check(lib.zkir_tape_upload_many(self._h, n, hdrs, blobs, sizes, ids))
+        for k, (h, _) in enumerate(parts):
+            self._tapes[ids[k]] = (h.n_inputs, h.n_outputs)
         return list(ids)
 
     def release(self, tid):

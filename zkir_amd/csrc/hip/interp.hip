@@ -299,22 +299,23 @@ zkir_interp_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, uint32_
         const uint32_t id = (op.code >> 8) ? (op.code >> 8) - 1u : check_k;
         if (bad && id < first_bad) first_bad = id;
         check_k++;
-      } else if (code == ZKIR_OP_OUTPUT) {
+      } else if (code == ZKIR_OP_OUTPUT || code == ZKIR_OP_OUTPUT_SCALED) {
         if (out) {  // nobody wants the outputs: skip the conversion too
           const Fr x = load_operand(op.a, acc, cx);
-          const Fr r = fr_redc(x);
+          // a tape value x is held as x * 2^256 mod p: the output times 2^256 is the held words as they are
+          const Fr r = code == ZKIR_OP_OUTPUT ? fr_redc(x) : x;
           if (live) {
             uint32_t* q = out + (size_t)op.dst * 8 * n_vectors;
 #pragma unroll
             for (int i = 0; i < 8; i++) q[(size_t)i * n_vectors] = r.l[i];
           }
         }
-      } else if (code == ZKIR_OP_INPUT) {
+      } else if (code == ZKIR_OP_INPUT || code == ZKIR_OP_INPUT_SCALED) {
         const uint32_t* q = in + (size_t)(op.a & ZKIR_INDEX_MASK) * 8 * n_vectors;
         Fr x;
 #pragma unroll
         for (int i = 0; i < 8; i++) x.l[i] = q[(size_t)i * n_vectors];
-        acc = fr_mul(x, fr_r2());
+        acc = code == ZKIR_OP_INPUT ? fr_mul(x, fr_r2()) : x;  // (the input times 2^-256 is held as the input's own words)
         store_operand(op.dst, acc, cx);
       } else if (code == ZKIR_OP_COPY) {
         acc = load_operand(op.a, acc, cx);

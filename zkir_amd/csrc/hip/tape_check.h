@@ -44,7 +44,7 @@ inline bool check_tape(const zkir_tape_hdr& h, const void* blob, size_t bytes, s
   if (h.n_lslots > ZKIR_MAX_LSLOTS) return bad("too many on-chip slots");
   if (h.flags & ~ZKIR_TAPE_F_STRANDS) return bad("unknown flag bits");
   const bool strands = (h.flags & ZKIR_TAPE_F_STRANDS) != 0;
-  if (h.reserved) return bad("reserved header word set");
+  if (h.n_scale_ops > h.n_mul_ops) return bad("more scaling products than products");
   uint32_t any_strand_ops = 0;
   for (uint32_t s = 0; s < ZKIR_MAX_STRANDS; s++) any_strand_ops |= h.strand_ops[s];
   if (strands) {
@@ -96,11 +96,11 @@ inline bool check_tape(const zkir_tape_hdr& h, const void* blob, size_t bytes, s
       barriers[strand]++;
       continue;
     }
-    if (code == ZKIR_OP_INPUT) {
+    if (code == ZKIR_OP_INPUT || code == ZKIR_OP_INPUT_SCALED) {
       if ((op.a >> ZKIR_KIND_SHIFT) != ZKIR_KIND_INPUT || (op.a & ZKIR_INDEX_MASK) >= h.n_inputs)
         return bad("input index out of range");
       if (!check_dest(h, op.dst, why)) return false;
-    } else if (code == ZKIR_OP_OUTPUT) {
+    } else if (code == ZKIR_OP_OUTPUT || code == ZKIR_OP_OUTPUT_SCALED) {
       if (op.dst >= h.n_outputs) return bad("output index out of range");
       if (!check_source(h, op.a, why)) return false;
     } else if (code == ZKIR_OP_CHECK) {

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -34,6 +35,7 @@ LowerOptions default_lower_options() {
   o.reorder = 1;
   o.window_cache = 1;
   o.order_ops = 1;
+  o.scaled_values = 1;
   return o;
 }
 
@@ -207,6 +209,7 @@ class Pass1 {
     note_statement();
     constrain_cell(cells_[pos], std::nullopt, value);
   }
+  Ref constant(const U256& v) { return const_of(v); }  // the pool entry of a value (made if it is new)
   void stream_ids_are_positions() { ids_are_positions_ = true; }
   void reserve_for(size_t n_statements) {  // a circuit of about this many statements is coming
     cells_.reserve(n_statements + 32);
@@ -661,6 +664,10 @@ class Pass1 {
   int eval_depth_ = 0, block_depth_ = 0;
 };
 
+// the ops whose `a` is an input element / whose `dst` is an output element, not a value
+inline bool is_input_op(uint8_t code) { return code == ZKIR_OP_INPUT || code == ZKIR_OP_INPUT_SCALED; }
+inline bool is_output_op(uint8_t code) { return code == ZKIR_OP_OUTPUT || code == ZKIR_OP_OUTPUT_SCALED; }
+
 // ---- pass 2: homes for values ----
 struct Home {
   uint32_t operand = ZKIR_OPERAND_NONE;  // GSLOT / LSLOT operand, or NONE when the value only lives in the accumulator
@@ -685,7 +692,7 @@ StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>&
   const size_t n = stream.size();
   auto op_at = [&](size_t i) -> const SOp& { return all[stream[i]]; };
   auto defines = [](const SOp& o) {
-    return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP && o.code != ZKIR_OP_BARRIER;
+    return !is_output_op(o.code) && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP && o.code != ZKIR_OP_BARRIER;
   };
   auto is_x = [&](Ref r) { return !xhome.empty() && (xhome[r] >> ZKIR_KIND_SHIFT) == ZKIR_KIND_XSLOT; };
 
@@ -708,7 +715,7 @@ StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>&
   for (size_t i = 0; i < n; i++) {
     const SOp& o = op_at(i);
     if (o.code == ZKIR_OP_BARRIER) continue;
-    if (o.code == ZKIR_OP_INPUT) {
+    if (is_input_op(o.code)) {
       def_at[o.dst] = (int64_t)i;
       continue;
     }
@@ -752,7 +759,7 @@ StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>&
       out.ops[i] = t;
       continue;
     }
-    if (o.code == ZKIR_OP_INPUT) {
+    if (is_input_op(o.code)) {
       t.a = ZKIR_OPERAND(ZKIR_KIND_INPUT, (uint32_t)o.a);
       t.b = ZKIR_OPERAND_NONE;
     } else {
@@ -764,7 +771,7 @@ StreamOut place_stream(const std::vector<SOp>& all, const std::vector<uint32_t>&
     if ((o.code == ZKIR_OP_MUL || o.code == ZKIR_OP_ADD || o.code == ZKIR_OP_CHECK) &&
         (t.b >> ZKIR_KIND_SHIFT) == ZKIR_KIND_ACC && (t.a >> ZKIR_KIND_SHIFT) != ZKIR_KIND_ACC)
       std::swap(t.a, t.b);
-    if (o.code == ZKIR_OP_OUTPUT) {
+    if (is_output_op(o.code)) {
       t.dst = (uint32_t)o.dst;
     } else if (o.code == ZKIR_OP_CHECK) {
       t.dst = src_operand(o.dst, i);
@@ -832,7 +839,7 @@ StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uin
   const size_t n = stream.size();
   auto op_at = [&](size_t i) -> const SOp& { return all[stream[i]]; };
   auto defines = [](const SOp& o) {
-    return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP && o.code != ZKIR_OP_BARRIER;
+    return !is_output_op(o.code) && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP && o.code != ZKIR_OP_BARRIER;
   };
   // The arrays of this function keep their memory from call to call (per thread): a campaign lowers thousands of
   // circuits per second and thread, and fresh megabytes per circuit are mostly page faults.
@@ -851,7 +858,7 @@ StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uin
   n_uses.assign(nv + 1, 0);
   auto sources = [&](const SOp& o, Ref out[3]) {
     out[0] = out[1] = out[2] = kNoRef;
-    if (o.code == ZKIR_OP_INPUT || o.code == ZKIR_OP_NOP || o.code == ZKIR_OP_BARRIER) return;
+    if (is_input_op(o.code) || o.code == ZKIR_OP_NOP || o.code == ZKIR_OP_BARRIER) return;
     out[0] = o.a;
     out[1] = o.b;
     if (o.code == ZKIR_OP_CHECK) out[2] = o.dst;
@@ -959,7 +966,7 @@ StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uin
     t.code = o.code;
     bool also_device = false;
     uint32_t device_home = 0;
-    if (o.code == ZKIR_OP_INPUT) {
+    if (is_input_op(o.code)) {
       t.a = ZKIR_OPERAND(ZKIR_KIND_INPUT, (uint32_t)o.a);
       t.b = ZKIR_OPERAND_NONE;
     } else {
@@ -969,7 +976,7 @@ StreamOut place_stream_cached(const std::vector<SOp>& all, const std::vector<uin
     if ((o.code == ZKIR_OP_MUL || o.code == ZKIR_OP_ADD || o.code == ZKIR_OP_CHECK) &&
         (t.b >> ZKIR_KIND_SHIFT) == ZKIR_KIND_ACC && (t.a >> ZKIR_KIND_SHIFT) != ZKIR_KIND_ACC)
       std::swap(t.a, t.b);
-    if (o.code == ZKIR_OP_OUTPUT) {
+    if (is_output_op(o.code)) {
       t.dst = (uint32_t)o.dst;
     } else if (o.code == ZKIR_OP_CHECK) {
       t.dst = src_operand(o.dst, i);
@@ -1061,9 +1068,11 @@ uint64_t device_slot_traffic(const std::vector<zkir_op>& ops, uint32_t one_word)
   for (const zkir_op& op : ops) {
     const uint32_t code = op.code & 0xffu;
     if (code == ZKIR_OP_NOP || code == ZKIR_OP_BARRIER) continue;
-    if (code == ZKIR_OP_INPUT) {
+    if (code == ZKIR_OP_INPUT_SCALED) {
+      // loaded straight into the accumulator: the operand registers keep what they hold
+    } else if (code == ZKIR_OP_INPUT) {
       tag_a = tag_b = UINT32_MAX;
-    } else if (code == ZKIR_OP_OUTPUT) {
+    } else if (code == ZKIR_OP_OUTPUT || code == ZKIR_OP_OUTPUT_SCALED) {
       fetch(op.a, &tag_a);
       continue;
     } else if (code == ZKIR_OP_COPY) {
@@ -1108,7 +1117,7 @@ std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std
   std::vector<uint32_t> order(n);
   for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
   if (nb < 3) return order;
-  auto defines = [](const SOp& o) { return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP; };
+  auto defines = [](const SOp& o) { return !is_output_op(o.code) && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP; };
   std::vector<int32_t> def_stmt(nv, -1);
   for (size_t b = 0; b < nb; b++)
     for (uint32_t i = begin[b]; i < begin[b + 1]; i++)
@@ -1120,7 +1129,7 @@ std::vector<uint32_t> schedule_statements(const std::vector<SOp>& ops, const std
     ext_begin[b] = (uint32_t)ext.size();
     for (uint32_t i = begin[b]; i < begin[b + 1]; i++) {
       const SOp& o = ops[i];
-      if (o.code == ZKIR_OP_INPUT || o.code == ZKIR_OP_NOP) continue;
+      if (is_input_op(o.code) || o.code == ZKIR_OP_NOP) continue;
       const Ref src[3] = {o.b, o.a, o.code == ZKIR_OP_CHECK ? o.dst : kNoRef};
       for (Ref r : src) {
         if (r < 0 || def_stmt[r] < 0 || def_stmt[r] == (int32_t)b) continue;
@@ -1254,10 +1263,10 @@ void order_within_statements(std::vector<SOp>& ops, const std::vector<uint32_t>&
     if (b < n && (begin.empty() || b > begin.back())) begin.push_back(b);
   if (begin.empty() || begin[0] != 0) begin.insert(begin.begin(), 0u);
   begin.push_back((uint32_t)n);
-  auto defines = [](const SOp& o) { return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP; };
+  auto defines = [](const SOp& o) { return !is_output_op(o.code) && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP; };
   auto sources = [](const SOp& o, Ref out[3]) {
     out[0] = out[1] = out[2] = kNoRef;
-    if (o.code == ZKIR_OP_INPUT || o.code == ZKIR_OP_NOP) return;
+    if (is_input_op(o.code) || o.code == ZKIR_OP_NOP) return;
     out[0] = o.a;
     out[1] = o.b;
     if (o.code == ZKIR_OP_CHECK) out[2] = o.dst;
@@ -1482,15 +1491,16 @@ Placement place_strands(const std::vector<SOp>& ops, int32_t nv) {
   pl.epoch.assign(n, -1);
   auto sources = [&](const SOp& o, Ref out[3]) {
     out[0] = out[1] = out[2] = kNoRef;
-    if (o.code == ZKIR_OP_INPUT || o.code == ZKIR_OP_NOP) return;
+    if (is_input_op(o.code) || o.code == ZKIR_OP_NOP) return;
     out[0] = o.a;
     out[1] = o.b;
     if (o.code == ZKIR_OP_CHECK) out[2] = o.dst;
   };
-  auto defines = [](const SOp& o) { return o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP; };
+  auto defines = [](const SOp& o) { return !is_output_op(o.code) && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP; };
   auto cost = [](uint8_t code) -> uint64_t {
     switch (code) {
       case ZKIR_OP_MUL: case ZKIR_OP_CHECK: case ZKIR_OP_INPUT: return 12;
+      case ZKIR_OP_OUTPUT_SCALED: case ZKIR_OP_INPUT_SCALED: return 1;
       case ZKIR_OP_OUTPUT: return 6;
       default: return 1;
     }
@@ -1630,7 +1640,7 @@ Placement place_strands(const std::vector<SOp>& ops, int32_t nv) {
   for (size_t i = 0; i < n; i++)
     if (defines(ops[i]) && ops[i].dst >= 0) def_op[ops[i].dst] = (int32_t)i;
   auto may_follow = [&](size_t i, uint32_t c) {  // could op i run right before its reader c, in c's strand?
-    if (ops[i].code == ZKIR_OP_INPUT || !defines(ops[i]) || n_readers[i] != 1) return false;
+    if (is_input_op(ops[i].code) || !defines(ops[i]) || n_readers[i] != 1) return false;
     if (pl.strand[c] == pl.strand[i]) return false;
     Ref src[3];
     sources(ops[i], src);
@@ -1712,6 +1722,186 @@ void write_tape(Tape& tape, const Pass1& p1, const std::vector<zkir_op>& out_ops
   tape.outputs = p1.outputs;
 }
 
+
+// ---- scaled values ---------------------------------------------------------------------------------------------
+// The device holds a tape value x as the words of x * 2^256 mod p (Montgomery form), so every output costs a
+// reduction (0.53 of a product) and every input a product.  A value v of the circuit may instead live on the tape as
+// v * 2^-256 ("scaled"; domain 1 below, plain is domain 0): its words on the device are v's own, INPUT_SCALED and
+// OUTPUT_SCALED move it in and out for nothing, sums of scaled values are scaled, and the product of a scaled and a
+// plain value is scaled.  What it costs: a product needs one plain factor, so a signal that is used as the plain
+// factor of some product gets a plain copy, made by one product with the constant 2^256 (once: the copy is a
+// value like any other).  This pass rewrites the single-assignment ops of a + - * circuit with a domain per value,
+// greedily in program order: every op takes the cheapest combination of its operands' domains (a copy that exists
+// is free, a constant is free in either domain, an input is free scaled), a value that flows into an output
+// through sums prefers to be scaled; of two factors that would both need a plain copy the one with more products
+// ahead of it gets it.  The rewrite is kept only if it is cheaper by that count than leaving every value plain (a
+// chain of squarings like the gadget's S-boxes gains nothing: both factors of x * x are the same value).
+// Returns the number of products added (0: ops left as they were).
+uint32_t assign_scales(Pass1& p1) {
+  const std::vector<SOp>& ops = p1.ops;
+  const size_t n = ops.size();
+  const int32_t nv = p1.n_values;
+  for (const SOp& o : ops) {
+    const uint8_t c = o.code;
+    if (c != ZKIR_OP_INPUT && c != ZKIR_OP_OUTPUT && c != ZKIR_OP_COPY && c != ZKIR_OP_NEG && c != ZKIR_OP_ADD && c != ZKIR_OP_SUB &&
+        c != ZKIR_OP_MUL && c != ZKIR_OP_CHECK && c != ZKIR_OP_NOP)
+      return 0;
+  }
+  // in products: a copy in the other domain is one product plus, on average, 1.3 more device-slot accesses (the copy
+  // is stored and read back), and on launches that spill a slot access costs about what 0.9 products cost (measured:
+  // the all-quadratic benchmark circuit lost 12 % with 331 copies for 1 099 free outputs, the circuit with
+  // constant factors won 7 % with 225 copies for 1 047)
+  static const float kConvert = std::getenv("ZKIR_SCALE_CONVERT_COST") ? (float)std::atof(std::getenv("ZKIR_SCALE_CONVERT_COST")) : 2.2f;
+  constexpr float kOutputPlain = 0.53f, kInputPlain = 1.0f;
+  U256 scale, scale_inv;  // 2^256 mod p and its inverse
+  {
+    U256 two128;
+    two128.w[2] = 1;
+    scale = fr::mul(two128, two128);
+    if (!fr::div(U256::from_u64(1), scale, &scale_inv)) return 0;
+  }
+  // which values flow into an output through sums, and how often each value is a factor
+  std::vector<uint8_t> to_output(nv, 0);
+  std::vector<uint32_t> factor_uses(nv, 0);
+  std::vector<int32_t> input_of(nv, -1);
+  uint32_t n_outputs = 0, n_inputs = 0;
+  for (size_t i = n; i-- > 0;) {
+    const SOp& o = ops[i];
+    switch (o.code) {
+      case ZKIR_OP_OUTPUT:
+        n_outputs++;
+        if (o.a >= 0) to_output[o.a] = 1;
+        break;
+      case ZKIR_OP_ADD: case ZKIR_OP_SUB: case ZKIR_OP_NEG: case ZKIR_OP_COPY:
+        if (o.dst >= 0 && to_output[o.dst]) {
+          if (o.a >= 0) to_output[o.a] = 1;
+          if (o.b >= 0) to_output[o.b] = 1;
+        }
+        break;
+      case ZKIR_OP_MUL: case ZKIR_OP_CHECK:
+        if (o.a >= 0) factor_uses[o.a]++;
+        if (o.b >= 0) factor_uses[o.b]++;
+        break;
+      case ZKIR_OP_INPUT:
+        n_inputs++;
+        input_of[o.dst] = o.a;
+        break;
+      default: break;
+    }
+  }
+  struct Rep {
+    Ref r[2] = {kNoRef, kNoRef};
+  };
+  std::vector<Rep> rep(nv);
+  std::vector<SOp> out;
+  out.reserve(n + n / 4);
+  std::vector<uint32_t> new_begin;
+  new_begin.reserve(p1.stmt_begin.size());
+  int32_t n_new = 0;
+  uint32_t n_scale = 0, n_out_plain = 0, n_in_plain = 0;
+  std::unordered_map<uint32_t, Ref> scaled_const;  // pool index -> pool entry of the constant times 2^-256
+
+  auto price = [&](Ref r, int e) -> float {
+    if (r < 0) return 0.f;  // a constant (or no operand)
+    if (rep[r].r[e] != kNoRef) return 0.f;
+    if (input_of[r] >= 0) return e ? 0.f : kInputPlain;
+    return kConvert;
+  };
+  auto get = [&](Ref r, int e) -> Ref {
+    if (r == kNoRef) return kNoRef;
+    if (is_const(r)) {
+      if (!e) return r;
+      auto it = scaled_const.find(const_index(r));
+      if (it != scaled_const.end()) return it->second;
+      const Ref s = p1.constant(fr::mul(p1.consts[const_index(r)], scale_inv));
+      scaled_const.emplace(const_index(r), s);
+      return s;
+    }
+    if (rep[r].r[e] != kNoRef) return rep[r].r[e];
+    const Ref v = n_new++;
+    if (input_of[r] >= 0) {
+      out.push_back({(uint8_t)(e ? ZKIR_OP_INPUT_SCALED : ZKIR_OP_INPUT), v, (Ref)input_of[r], kNoRef});
+      n_in_plain += e ? 0 : 1;
+    } else {
+      // the other copy times 2^256 (scaled -> plain) or 2^-256 (plain -> scaled)
+      out.push_back({ZKIR_OP_MUL, v, rep[r].r[1 - e], p1.constant(e ? scale_inv : scale)});
+      n_scale++;
+    }
+    rep[r].r[e] = v;
+    return v;
+  };
+  auto define = [&](Ref old, int e) -> Ref {
+    const Ref v = n_new++;
+    rep[old].r[e] = v;
+    return v;
+  };
+  size_t next_begin = 0;
+  for (size_t i = 0; i < n; i++) {
+    while (next_begin < p1.stmt_begin.size() && p1.stmt_begin[next_begin] <= i) {
+      if (p1.stmt_begin[next_begin] == i && (new_begin.empty() || new_begin.back() != out.size())) new_begin.push_back((uint32_t)out.size());
+      next_begin++;
+    }
+    const SOp& o = ops[i];
+    switch (o.code) {
+      case ZKIR_OP_NOP: case ZKIR_OP_INPUT:  // (an input is loaded where it is first read, in the domain it is read in)
+        break;
+      case ZKIR_OP_OUTPUT: {
+        const int e = price(o.a, 1) <= price(o.a, 0) + kOutputPlain ? 1 : 0;
+        const Ref a = get(o.a, e);
+        out.push_back({(uint8_t)(e ? ZKIR_OP_OUTPUT_SCALED : ZKIR_OP_OUTPUT), o.dst, a, kNoRef});
+        n_out_plain += e ? 0 : 1;
+        break;
+      }
+      case ZKIR_OP_ADD: case ZKIR_OP_SUB: case ZKIR_OP_NEG: case ZKIR_OP_COPY: {
+        float c[2];
+        for (int e = 0; e < 2; e++) c[e] = price(o.a, e) + price(o.b, e) + (!e && to_output[o.dst] ? kOutputPlain : 0.f);
+        const int e = c[1] < c[0] ? 1 : 0;
+        const Ref a = get(o.a, e), b = get(o.b, e);
+        out.push_back({o.code, define(o.dst, e), a, b});
+        break;
+      }
+      case ZKIR_OP_MUL: case ZKIR_OP_CHECK: {
+        // (domain of a, domain of b); the product's domain is their sum
+        static const int kA[3] = {0, 1, 0}, kB[3] = {0, 0, 1};
+        float best = 1e30f;
+        int pick = 0;
+        for (int k = 0; k < 3; k++) {
+          const int ea = kA[k], eb = kB[k], e = ea + eb;
+          float c = price(o.a, ea) + (o.b == o.a && ea == eb ? 0.f : price(o.b, eb));
+          if (o.code == ZKIR_OP_CHECK) c += price(o.dst, e);
+          else if (!e && to_output[o.dst]) c += kOutputPlain;
+          // of two factors that would both need a plain copy, the one with more products ahead gets it
+          if (k == 1 && o.b >= 0 && rep[o.b].r[0] == kNoRef) c -= 1e-4f * (float)std::min<uint32_t>(factor_uses[o.b], 1000u);
+          if (k == 2 && o.a >= 0 && rep[o.a].r[0] == kNoRef) c -= 1e-4f * (float)std::min<uint32_t>(factor_uses[o.a], 1000u);
+          if (c < best) {
+            best = c;
+            pick = k;
+          }
+        }
+        const int ea = kA[pick], eb = kB[pick];
+        const Ref a = get(o.a, ea), b = get(o.b, eb);
+        if (o.a >= 0) factor_uses[o.a]--;
+        if (o.b >= 0) factor_uses[o.b]--;
+        if (o.code == ZKIR_OP_CHECK) out.push_back({ZKIR_OP_CHECK, get(o.dst, ea + eb), a, b});
+        else out.push_back({ZKIR_OP_MUL, define(o.dst, ea + eb), a, b});
+        break;
+      }
+      default: return 0;
+    }
+  }
+  const float cost_scaled = kConvert * n_scale + kOutputPlain * n_out_plain + kInputPlain * n_in_plain;
+  const float cost_plain = kOutputPlain * n_outputs + kInputPlain * n_inputs;
+  if (std::getenv("ZKIR_SCALE_DEBUG"))
+    fprintf(stderr, "assign_scales: %u copies, %u of %u outputs plain, %u of %u inputs plain: cost %.1f against %.1f\n", n_scale,
+            n_out_plain, n_outputs, n_in_plain, n_inputs, cost_scaled, cost_plain);
+  if (!(cost_scaled < 0.97f * cost_plain)) return 0;
+  new_begin.push_back((uint32_t)out.size());
+  p1.ops.swap(out);
+  p1.stmt_begin.swap(new_begin);
+  p1.n_values = n_new;
+  return n_scale;
+}
+
 void check_options(const LowerOptions& opts_) {
   if (opts_.n_lslots > ZKIR_MAX_LSLOTS) throw LowerError(ZKIR_LOWER_BAD_AST, "n_lslots above ZKIR_MAX_LSLOTS");
   if (opts_.strands != 0 && opts_.strands != ZKIR_STRANDS && opts_.strands != ZKIR_MAX_STRANDS)
@@ -1720,6 +1910,7 @@ void check_options(const LowerOptions& opts_) {
 
 // pass 2 and the tape itself, from the single-assignment ops of pass 1
 Tape place_tape(Pass1& p1, const LowerOptions& opts_) {
+  const uint32_t n_scale_ops = opts_.scaled_values ? assign_scales(p1) : 0;
   if (opts_.order_ops) order_within_statements(p1.ops, p1.stmt_begin, p1.n_values);
   const std::vector<SOp>& ops = p1.ops;
   const size_t n = ops.size();
@@ -1743,6 +1934,7 @@ Tape place_tape(Pass1& p1, const LowerOptions& opts_) {
   h.n_outputs = (uint32_t)p1.n_outputs;
   h.n_consts = (uint32_t)p1.consts.size();
   h.n_constraints = n_checks;
+  h.n_scale_ops = n_scale_ops;
   std::vector<uint32_t> triples((size_t)n_checks * 3, 0);
 
   if (opts_.strands && plain_ops_only && n_checks < (1u << 24) - 1) {
@@ -1759,7 +1951,7 @@ Tape place_tape(Pass1& p1, const LowerOptions& opts_) {
       for (int s = 0; s < (int)ZKIR_STRANDS; s++) {
         std::vector<uint32_t> keep;
         for (uint32_t i : pl.order[s]) {
-          if (ops[i].code == ZKIR_OP_OUTPUT || ops[i].code == ZKIR_OP_CHECK) {
+          if (is_output_op(ops[i].code) || ops[i].code == ZKIR_OP_CHECK) {
             any_in_last = any_in_last || pl.epoch[i] == pl.n_epochs - 1;
             pl.strand[i] = (uint8_t)(s + (int)ZKIR_STRANDS);
             pl.epoch[i] += 1;
@@ -1784,12 +1976,12 @@ Tape place_tape(Pass1& p1, const LowerOptions& opts_) {
     };
     for (size_t i = 0; i < n; i++) {
       const SOp& o = ops[i];
-      if (o.code != ZKIR_OP_INPUT) {
+      if (!is_input_op(o.code)) {
         note(o.a, i);
         note(o.b, i);
         if (o.code == ZKIR_OP_CHECK) note(o.dst, i);
       }
-      const bool defines = o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP;
+      const bool defines = !is_output_op(o.code) && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP;
       if (defines && o.dst >= 0) def_op[o.dst] = (int32_t)i;
     }
     std::vector<uint32_t> xhome(nv, ZKIR_OPERAND_NONE);
@@ -1797,7 +1989,7 @@ Tape place_tape(Pass1& p1, const LowerOptions& opts_) {
     bool fits = true;
     for (size_t i = 0; i < n && fits; i++) {
       const SOp& o = ops[i];
-      const bool defines = o.code != ZKIR_OP_OUTPUT && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP;
+      const bool defines = !is_output_op(o.code) && o.code != ZKIR_OP_CHECK && o.code != ZKIR_OP_NOP;
       if (!defines || o.dst < 0 || !crosses[o.dst]) continue;
       uint32_t slot = UINT32_MAX;
       for (uint32_t s = 0; s < slot_free_from.size(); s++)
