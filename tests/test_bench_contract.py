@@ -7,11 +7,17 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+CURRENT_ROUND = 3
+
+
 def latest_line():
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))
-    assert paths, "no committed bench line"
+    """The newest committed output of `python bench.py` on an MI355X: the last (by name) bench line of the current
+    round under profiles/.  A round that commits no line of its own fails here: the checks below would otherwise
+    keep passing on an old file."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r%02d_*bench*.json" % CURRENT_ROUND)))
+    assert paths, "no bench line of round %d under profiles/" % CURRENT_ROUND
     with open(paths[-1]) as f:
-        return json.loads(f.read())
+        return json.loads(f.read().strip().splitlines()[-1])
 
 
 def test_bench_line_schema():
@@ -32,9 +38,24 @@ def test_bench_line_schema():
     cfg = d["config"]
     per_step = cfg["n_constraints"] * cfg["vectors_per_gpu"] * d["n_gpus"]
     assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
-    # the counted products: one per Mul op and one per check, 128 high products each
-    fr = (cfg["n_mul_ops"] + cfg["n_constraints"]) * cfg["vectors_per_gpu"]
+    # the counted products (bench.products_of): one per MUL op of the circuit and one per constraint that multiplies;
+    # a constraint `value * 1 == signal` is compared without a product, a product lower added to rescale a value is
+    # not the circuit's: 128 high products each
+    fr = (cfg["n_mul_ops"] + cfg["n_constraints"] - cfg["n_constraints_times_one"]) * cfg["vectors_per_gpu"]
     assert abs(r["achieved"] * 1e12 - 128.0 * fr / (r["kernel_ms"] * 1e-3)) / (r["achieved"] * 1e12) < 1e-6
+    # the headline circuit is the all-quadratic one: (next to) no constraint against the constant 1
+    assert cfg["n_constraints_times_one"] <= 0.05 * cfg["n_constraints"]
+    # the traffic figure is the counter passes' entry for this workload
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        t = json.load(f)
+    assert r["traffic"] is not None
+    assert any(abs(ent["bytes_per_launch"] - r["traffic"]) < 1 and ent["source"].startswith("profiles/r%02d_" % CURRENT_ROUND)
+               for key, ent in t.items() if not key.startswith("_"))
+    # the comparison entry keeps the earlier rounds' circuit, the campaign sample says where its seconds went
+    also = {e["workload"].split(":")[0].split(" with ")[0].split(" as ")[0] + ("/old" if " with the earlier" in e["workload"] else ""): e
+            for e in d["also"]}
+    assert also["configuration 2/old"]["n_constraints_times_one"] > 100
+    assert set(also["configuration 4 (sample)"]["phases_rank0"]) >= {"generate_thread_s", "lower_thread_s", "upload_s", "evaluate_s", "reduce_s"}
 
 
 def test_traffic_file_matches_profiles():
