@@ -107,6 +107,8 @@ def test_products_are_mul_ops_plus_constraints_that_multiply():
     ops, consts = t.ops(), t.consts()
     by_one = sum(1 for code, _, _, b in ops if code & 0xFF == 48 and b >> 29 == 2 and consts[b & 0x1FFFFFFF] == 1)
     assert by_one > 100 and bench.checks_by_one(t) == by_one
-    assert bench.products_of(t) == t.hdr.n_mul_ops + t.hdr.n_constraints - by_one
+    # (the products lower adds to rescale values are not the circuit's)
+    assert t.hdr.n_scale_ops > 100 and bench.products_of(t) == t.hdr.n_mul_ops - t.hdr.n_scale_ops + t.hdr.n_constraints - by_one
+    assert bench.workload_tape(z).hdr.n_scale_ops == 0  # the all-quadratic circuit stays plain: copies would outnumber its savings
     g = bench.gadget_tape(z, 5, 4)
     assert bench.checks_by_one(g) == 0 and bench.products_of(g) == g.hdr.n_mul_ops + g.hdr.n_constraints
