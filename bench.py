@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, datasheet
 MULHI_PEAK_THEORETICAL = 256 * 4 * 16 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock: one v_mul_hi_u32 per lane per clock
 
 
-def workload_tape(z, signal_window=0, linear_terms=1, signal_factors=1):
+def workload_tape(z, signal_window=0, linear_terms=1, signal_factors=1, for_cpu=False):
     """configs[1] of BASELINE.json: about 1k rank-1 constraints `out <== lin*lin + lin`, about 1k
     products and about 2k additions/subtractions over 16 inputs.  linear_terms=1 (each `lin` is one
     signal or constant) gives that mix; 2 gives sums of two, i.e. twice the additions and more
@@ -46,6 +46,12 @@ def workload_tape(z, signal_window=0, linear_terms=1, signal_factors=1):
     g.forced_inputs, g.inputs_readable, g.arithmetic_only, g.quadratic_aware = 16, 1, 1, 1
     g.no_loops, g.safe_array_index = 1, 1
     o = z.default_lower_options()
+    if for_cpu:
+        # The same circuit as the CPU checker runs it fastest: statements in program order.  The order lower picks for
+        # the GPU scatters the output stores over the output buffer, which costs the host cores their stride
+        # prefetching (measured on the GPU box's 16 cores: 0.16 G checks/s in program order, 0.08 G in the GPU's order).
+        o.reorder = o.window_cache = o.order_ops = o.scaled_values = 0
+        return z.Lowerer(z.Generator(WORKLOAD_SEED, g).generate(), o).lower()
     for k in ("n_lslots", "window_lifetime", "use_acc", "reuse_slots", "strands", "max_xslots", "reorder", "window_cache", "order_ops", "scaled_values"):  # experiment knobs
         if os.environ.get("ZKIR_BENCH_" + k.upper()):
             setattr(o, k, int(os.environ["ZKIR_BENCH_" + k.upper()]))
@@ -467,13 +473,16 @@ def main():
             threads = host_threads()
             sample = min(n, (64 if gadget else 8192) * min(threads, 32))  # 10 to 30 s of CPU work in all
             inp_s = np.ascontiguousarray(inp[:, :, :sample].cpu().numpy().view(np.uint32))
-            cps, dt = cpu_baseline(tape, inp_s, threads)
+            cpu_tape = tape if gadget else workload_tape(z, args.signal_window, args.linear_terms, 0 if args.constant_factors else 1, for_cpu=True)
+            assert cpu_tape.hdr.n_constraints == h.n_constraints and cpu_tape.hdr.n_inputs == h.n_inputs
+            cps, dt = cpu_baseline(cpu_tape, inp_s, threads)
             one = max(1, sample // 4)
-            cps1, dt1 = cpu_baseline(tape, np.ascontiguousarray(inp_s[:, :, :one]), 1)
+            cps1, dt1 = cpu_baseline(cpu_tape, np.ascontiguousarray(inp_s[:, :, :one]), 1)
             line["cpu_baseline"] = {"value": cps, "unit": "checks/s", "cores": threads, "kind": "port",
                                     "host_cpus": os.cpu_count(),
-                                    "sample": "first %d vectors of the same batch, %d threads (every core this process may "
-                                              "use; the machine shows %s), %.1f s" % (sample, threads, os.cpu_count(), dt),
+                                    "sample": "first %d vectors of the same batch, the same circuit lowered in program order (the "
+                                              "order the CPU runs fastest), %d threads (every core this process may use; the machine "
+                                              "shows %s), %.1f s" % (sample, threads, os.cpu_count(), dt),
                                     "one_core": {"value": cps1, "sample": "first %d vectors, 1 thread, %.1f s" % (one, dt1)}}
         print(json.dumps(line), flush=True)
     if ctx is not None:

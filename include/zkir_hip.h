@@ -450,6 +450,23 @@ int32_t zkir_eval_multi_dev_faults(zkir_ctx* ctx, const zkir_tape_id* tapes, uin
                                    uint64_t N_per_tape, uint64_t* per_tape_unsat_dev, uint64_t* per_tape_faults_dev,
                                    uint64_t* result_dev, void* stream);
 
+/* ------------------------------------------------------- several GPUs, one process */
+/* The campaign's one exchange step for a host process that drives several GPUs itself (one zkir_ctx per device,
+ * circuit i on device i mod n: units are independent, nothing else is exchanged): RCCL communicators over the given
+ * devices (ncclCommInitAll), one all-reduce (sum) of `n_counters` uint64 counters per device and one all-gather of
+ * each device's list of divergent circuit ids (at most `id_capacity` each; the count travels first, the payload is
+ * padded).  No counterpart in the reference, whose only caller is one process with one backend (src/main.rs:81-92).
+ *   counters [n_devices][n_counters], ids [n_devices][id_capacity], n_ids [n_devices]          (host memory, in)
+ *   totals [n_counters], all_ids [n_devices * id_capacity] sorted without repeats, *n_all_ids   (host memory, out)
+ * ZKIR_E_UNSUPPORTED when no RCCL library can be loaded, ZKIR_E_LIMIT when a device brings more ids than the
+ * capacity.  A process per GPU (torch.distributed, MPI) does the same exchange with its own collectives. */
+typedef struct zkir_reducer zkir_reducer;
+int32_t zkir_reducer_create(const int32_t* devices, uint32_t n_devices, uint32_t n_counters, uint32_t id_capacity, zkir_reducer** out);
+int32_t zkir_reducer_reduce(zkir_reducer* r, const uint64_t* counters, const uint32_t* ids, const uint32_t* n_ids, uint64_t* totals,
+                            uint32_t* all_ids, uint32_t* n_all_ids);
+const char* zkir_reducer_last_error(const zkir_reducer* r);
+int32_t zkir_reducer_destroy(zkir_reducer* r);
+
 /* Faults (division by zero at run time) seen by the last synchronous call. */
 int32_t zkir_last_faults(const zkir_ctx* ctx, uint64_t* faults);
 

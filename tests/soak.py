@@ -11,7 +11,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 ctx = z.Context(0)
 rnd = random.Random(20240611)
 special = [0, 1, 2, F.P - 1, F.P - 2, F.HALF, F.HALF + 1, (1 << 64) - 1, 1 << 253, 253, 254, 255, F.P - 253, F.P - 254]
-done = rejected = bad = full = multi = stranded = 0
+done = rejected = bad = full = multi = stranded = scaled = 0
 group = []
 t0 = time.time()
 for it in range(N):
@@ -28,6 +28,7 @@ for it in range(N):
     g.enable_if = rnd.choice([0, 0, 2])
     g.max_linear_terms = rnd.choice([0, 1])
     g.signal_window = rnd.choice([0, 0, 4])
+    g.signal_factors = rnd.choice([0, 1])
     o = z.default_lower_options()
     o.n_lslots = rnd.choice([0, 1, 2, 3, 4, 4, 8, 16])
     o.use_acc = rnd.choice([0, 1, 1, 1])
@@ -41,6 +42,7 @@ for it in range(N):
     o.reorder = rnd.choice([0, 1, 1])
     o.window_cache = rnd.choice([0, 1, 1])
     o.order_ops = rnd.choice([0, 1, 1])
+    o.scaled_values = rnd.choice([0, 1, 1])  # (the pass keeps its rewrite only where it pays: ZKIR_SCALE_CONVERT_COST=0.1 in the environment makes it keep almost all)
     seed = rnd.randrange(1, 1 << 62)
     try:
         tape = z.Lowerer(z.Generator(seed, g).generate(), o).lower()
@@ -97,10 +99,11 @@ for it in range(N):
     done += 1
     stranded += tape.hdr.flags & 1
     codes = {c & 0xFF for c, _, _, _ in tape.ops()}
-    full += bool(codes - {0, 1, 2, 3, 4, 16, 17, 18, 48})
+    full += bool(codes - {0, 1, 2, 3, 4, 7, 8, 9, 16, 17, 18, 48})
+    scaled += bool(codes & {8, 9})
     if it % 100 == 0:
         print("iter", it, "evaluated", done, "rejected", rejected, "mismatches", bad, "%.0fs" % (time.time() - t0), flush=True)
 os.environ.pop("ZKIR_INTERP", None)
-print("SOAK done: evaluated %d circuits (%d with non-arithmetic operators, %d as strand tapes) and %d multi-tape launches, "
-      "rejected %d, mismatches %d" % (done, full, stranded, multi, rejected, bad))
+print("SOAK done: evaluated %d circuits (%d with non-arithmetic operators, %d as strand tapes, %d with scaled values) and %d "
+      "multi-tape launches, rejected %d, mismatches %d" % (done, full, stranded, scaled, multi, rejected, bad))
 sys.exit(1 if bad else 0)

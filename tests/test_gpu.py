@@ -807,3 +807,22 @@ def test_campaign_sized_launch_with_planted_failures_and_faults(ctx, interpreter
     assert sum(1 for k in planted if got[k] > 0) >= 1 and all(g == 0 for k, g in enumerate(got) if k not in planted)
     for t in tids:
         ctx.release(t)
+
+
+@pytest.mark.gpu
+def test_reducer_over_rccl_sums_counters_and_unites_ids():
+    """zkir_reducer_*: the campaign's exchange step behind the C ABI (RCCL communicators made in this process).
+    With the one GPU of this box the collectives run over a single rank; the sum, the count-first padded gather,
+    the sorted union and the capacity check are the same code for any number of devices."""
+    from zkir_amd import api
+    r = api.Reducer([0], 6, 16)
+    try:
+        totals, ids = r.reduce([[5, 0, 2**40 + 3, 1, 0, 7]], [[9, 3, 3, 12]])
+        assert totals == [5, 0, 2**40 + 3, 1, 0, 7] and ids == [3, 9, 12]
+        totals, ids = r.reduce([[1, 2, 3, 4, 5, 6]], [[]])          # a second call, nothing divergent
+        assert totals == [1, 2, 3, 4, 5, 6] and ids == []
+        with pytest.raises(api.ZkirError) as e:
+            r.reduce([[0] * 6], [list(range(17))])
+        assert e.value.code == api.E_LIMIT
+    finally:
+        r.close()

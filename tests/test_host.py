@@ -488,3 +488,17 @@ def test_build_entry_does_not_import_the_package():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+
+
+def test_reducer_refuses_bad_arguments_and_needs_a_gpu():
+    """zkir_reducer_create: argument checks come before any device work; with no GPU it answers NODEVICE."""
+    from zkir_amd import api
+    for devices, counters, cap in (([], 4, 8), ([0, 0], 4, 8), ([0], 0, 8), ([0], 4, (1 << 20) + 1)):
+        with pytest.raises(api.ZkirError) as e:
+            api.Reducer(devices, counters, cap)
+        assert e.value.code in (api.E_INVALID, api.E_NODEVICE)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(api.ZkirError) as e:
+            api.Reducer([0], 4, 8)
+        assert e.value.code == api.E_NODEVICE

@@ -3,3 +3,4 @@ from .api import (Circuit, CircomTranspiler, NoirTranspiler, Context, Generator,
                   LowerRejected, Tape, TapeHdr, ZkirError, default_generator_config, default_lower_options,
                   generate_lower_many, pack_inputs, poseidon_style_gadget, rng_stream, unpack_outputs)
 from .api import E_INVALID, E_LIMIT, E_LOWER  # noqa: F401
+from .api import Reducer  # noqa: F401

@@ -100,6 +100,9 @@ def _load():
         "zkir_eval_multi_dev": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p],
         "zkir_eval_multi_dev_faults": [c_void_p, P(c_uint32), c_uint32, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p],
         "zkir_last_faults": [c_void_p, P(c_uint64)],
+        "zkir_reducer_create": [P(c_int32), c_uint32, c_uint32, c_uint32, P(c_void_p)],
+        "zkir_reducer_reduce": [c_void_p, P(c_uint64), P(c_uint32), P(c_uint32), P(c_uint64), P(c_uint32), P(c_uint32)],
+        "zkir_reducer_destroy": [c_void_p],
         "zkir_measure_int_mul_rate": [c_void_p, c_int32, P(c_double)],
         "zkir_measure_fr_mul_rate": [c_void_p, P(c_double)],
         "zkir_measure_fr_mul_rate29": [c_void_p, P(c_double)],
@@ -114,6 +117,8 @@ def _load():
     lib.zkir_tape_free.restype = None
     lib.zkir_last_error.argtypes = [c_void_p]
     lib.zkir_last_error.restype = c_char_p
+    lib.zkir_reducer_last_error.argtypes = [c_void_p]
+    lib.zkir_reducer_last_error.restype = c_char_p
     lib.zkir_host_last_error.argtypes = []
     lib.zkir_host_last_error.restype = c_char_p
     return lib
@@ -303,6 +308,40 @@ def generate_lower_many(seeds, configs=None, options=None, threads=1):
     _host_check(lib.zkir_generate_lower_many(c_seeds, c_cfgs, n, byref(options) if options is not None else None,
                                              threads, tapes, classes))
     return [(classes[k], Tape(c_void_p(tapes[k])) if tapes[k] else None) for k in range(n)]
+
+
+class Reducer:
+    """zkir_reducer: the campaign's exchange step over RCCL for one process that drives several GPUs."""
+
+    def __init__(self, devices, n_counters, id_capacity):
+        self.n, self.n_counters, self.capacity = len(devices), n_counters, id_capacity
+        h = c_void_p()
+        rc = lib.zkir_reducer_create((c_int32 * self.n)(*devices), self.n, n_counters, id_capacity, byref(h))
+        if rc != OK:
+            raise ZkirError(rc, "zkir_reducer_create")
+        self._h = h
+
+    def reduce(self, counters, id_lists):
+        """counters: one list of n_counters ints per device; id_lists: one list of divergent ids per device.
+        Returns (totals, sorted union of the ids)."""
+        flat = (c_uint64 * (self.n * self.n_counters))(*[v for row in counters for v in row])
+        ids = (c_uint32 * max(1, self.n * self.capacity))()
+        n_ids = (c_uint32 * self.n)(*[len(l) for l in id_lists])
+        for k, l in enumerate(id_lists):
+            for j, v in enumerate(l[:self.capacity]):
+                ids[k * self.capacity + j] = v
+        totals = (c_uint64 * self.n_counters)()
+        out = (c_uint32 * max(1, self.n * self.capacity))()
+        n_out = c_uint32()
+        rc = lib.zkir_reducer_reduce(self._h, flat, ids, n_ids, totals, out, byref(n_out))
+        if rc != OK:
+            raise ZkirError(rc, lib.zkir_reducer_last_error(self._h).decode())
+        return list(totals), list(out[:n_out.value])
+
+    def close(self):
+        if self._h:
+            lib.zkir_reducer_destroy(self._h)
+            self._h = None
 
 
 def host_phase_seconds():

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzkir_hip.so")
 
 DEVICE_SOURCES = ["hip/interp.hip"]
-HOST_SOURCES = ["hip/runtime.cpp", "host/capi.cpp", "host/generator.cpp", "host/circom.cpp", "host/noir.cpp", "host/lower.cpp",
+HOST_SOURCES = ["hip/runtime.cpp", "hip/reducer.cpp", "host/capi.cpp", "host/generator.cpp", "host/circom.cpp", "host/noir.cpp", "host/lower.cpp",
                 "host/sexpr.cpp", "host/gadget.cpp", "host/fr_host.cpp"]
 
 
@@ -44,7 +44,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
     if force or _newer(objs, LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
