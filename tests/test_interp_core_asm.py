@@ -65,6 +65,7 @@ def run_lane(ops, consts, inputs, n_outputs, n_lslots, n_gslots, vec, wave=0, la
     bit = 1 << lane
     operands = {
         "%[ops]": OPS_BASE, "%[n_ops]": len(ops), "%[consts]": CST_BASE, "%[n_consts]": len(consts), "%[one_word]": one_word_of(consts),
+        "%[rot]": 0xFFFFFFFF, "%[rot_shift]": 12,
         "%[gslots]": gs, "%[gslot_bytes]": gs_bytes,
         "%[lds_base]": LDS_BASE + (8192 if victim else 0),  # the victim row, if any, comes first
         "%[evict_below]": 0x20000000 if victim else 0,
@@ -408,10 +409,12 @@ def test_operand_registers_are_reused_and_invalidated():
 
 
 # ---- strand tapes: four wavefronts, one lane of each, sharing LDS and the output buffer -------------
-def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, n_xslots, vec, lane=0):
+def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, n_xslots, vec, lane=0, rot=0xFFFFFFFF,
+                clock_step=0, prio_logs=None):
     """The same lane of the wavefronts of a workgroup (four or eight: len(strand_ops)), each running its strand of
     `ops` from barrier to barrier in turn, with the operands the kernel around the stream gives them (eight
-    wavefronts keep two sets of slot rows: wavefronts 4..7 use the second).
+    wavefronts keep two sets of slot rows: wavefronts 4..7 use the second).  rot: the workgroup's phase in the
+    priority turns (0xFFFFFFFF: none); the model's clock advances by clock_step per barrier.
     Returns (outputs, unsat summed over the strands, smallest first-unsat)."""
     n_str = len(strand_ops)
     sets = 2 if n_str == 8 else 1
@@ -443,7 +446,7 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
             "%[lds_base]": LDS_BASE + (w >> 2) * n_lslots * 8192, "%[evict_below]": 0,
             "%[in_base]": IN_BASE, "%[out_base]": OUT_BASE, "%[n4]": 4 * n_vec, "%[live]": 0x8000000000000001 | (1 << lane),
             "%[v_lo]": (w & 3) * 2048 + lane * 16, "%[v_vec4]": 4 * vec,
-            "%[xbase]": LDS_BASE + sets * n_lslots * 8192, "%[v_x]": lane * 16,
+            "%[xbase]": LDS_BASE + sets * n_lslots * 8192, "%[v_x]": lane * 16, "%[rot]": rot, "%[rot_shift]": 12,
         }
         ln = IM.Lane(mem, LDS_BASE + sets * n_lslots * 8192 + n_xslots * 2048, lane, operands, set(range(G.VB, G.V_LAST + 1)),
                      set(range(G.S_FIRST, G.S_LAST + 1)), result_operands=("%[unsat]", "%[first]"))
@@ -455,10 +458,13 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
     while any(pc is not None for pc in pcs):
         for w in range(n_str):
             if pcs[w] is not None:
+                lanes[w].clock = (1 << 40) + clock_step * arrived[w]
                 pcs[w] = lanes[w].run(PROG, LABELS, pc=pcs[w], stop_at_barrier=True)
                 arrived[w] += pcs[w] is not None
         assert len({a for a, pc in zip(arrived, pcs) if pc is not None}) <= 1, "wavefronts wait at different barriers"
     assert len(set(arrived)) == 1, "strands passed different numbers of barriers"
+    if prio_logs is not None:
+        prio_logs.extend(ln.prio_log for ln in lanes)
     outs = []
     for s in range(n_outputs):
         limbs = [out_region.words.get(OUT_BASE + 4 * ((s * 8 + l) * n_vec + vec)) for l in range(8)]
@@ -466,6 +472,36 @@ def run_strands(ops, strand_ops, consts, inputs, n_outputs, n_lslots, n_gslots, 
     unsat = sum(ln.operand_written["%[unsat]"] for ln in lanes)
     first = min(ln.operand_written["%[first]"] for ln in lanes)
     return outs, unsat, first
+
+
+def test_priority_turns_of_a_strand_tape():
+    """With turns on, every barrier sets the wavefront's priority to ((clock >> shift) + phase) & 3: the workgroups of
+    a CU (phases 0..3) hold four different priorities at any time, each priority for a quarter of the time; results do
+    not change; without turns the stream never touches the priority."""
+    import zkir_amd as z
+    o = z.default_lower_options()
+    o.strands = 4
+    t = z.Lowerer(z.poseidon_style_gadget(4, 6, 2), o).lower()
+    ops, consts, so = t.ops(), t.consts(), list(t.hdr.strand_ops)[:4]
+    rnd = random.Random(5)
+    inputs = [[rnd.randrange(F.P) for _ in range(4)] for _ in range(2)]
+    want, _, _ = F.eval_tape_one(ops, consts, inputs[1], strand_ops=so)
+    n_barriers = sum(1 for op in ops[:so[0]] if op[0] & 0xFF == F.OP_BARRIER)
+    assert n_barriers >= 4
+    per_phase = []
+    for phase in (0, 1, 2, 3, 0xFFFFFFFF):
+        logs = []
+        outs, unsat, _ = run_strands(ops, so, consts, inputs, t.hdr.n_outputs, t.hdr.n_lslots, t.hdr.n_gslots, t.hdr.n_xslots,
+                                     1, 9, rot=phase, clock_step=1 << 12, prio_logs=logs)
+        assert outs == [want[k] for k in range(t.hdr.n_outputs)] and unsat == 0
+        if phase == 0xFFFFFFFF:
+            assert all(log == [0] for log in logs)  # only the reset at the end of the stream
+        else:
+            # the clock advances one turn per barrier in this run: barrier k sets (k + phase) & 3; then the final reset
+            assert all(log == [(k + phase) & 3 for k in range(n_barriers)] + [0] for log in logs)
+            per_phase.append(logs[0][:n_barriers])
+    for k in range(n_barriers):
+        assert sorted(p[k] for p in per_phase) == [0, 1, 2, 3]
 
 
 @pytest.mark.parametrize("n_strands", [4, 8])

@@ -99,6 +99,8 @@ TAG_A, TAG_B = "s%d" % (SB + 42), "s%d" % (SB + 43)  # operand words whose value
 CST8 = "s[%d:%d]" % (SB + 44, SB + 51)
 cst_word = lambda j: "s%d" % (SB + 44 + j)
 TAG_V = "s%d" % (SB + 41)  # device-slot operand word whose value sits in the victim row of LDS
+NOW = "s[%d:%d]" % (SB + 36, SB + 37)  # the constant-rate clock, read at a barrier (strand tapes with priority turns):
+NOW_LO = "s%d" % (SB + 36)             # the temporaries T2 and T3, which hold nothing across ops
 S_LAST = SB + 51
 assert S_LAST <= 99  # s100 and above are reserved by the compiler on this target
 
@@ -115,6 +117,9 @@ IN_VLO, IN_VVEC = "%[v_lo]", "%[v_vec4]"
 IN_EVICT = "%[evict_below]"  # 0x20000000 when the launch has a victim row, 0 when it has none
 IN_XBASE, IN_VX = "%[xbase]", "%[v_x]"  # strand tapes: LDS address of the exchange slots, lane * 16
 IN_ONE = "%[one_word]"  # the operand word of the tape's constant 1 (0xffffffff when its pool holds none)
+IN_ROT = "%[rot]"      # which of the workgroups resident on its CU this one is (0..3): the phase of its priority
+                       # turns; -1: no turns
+IN_ROTSH = "%[rot_shift]"  # a turn lasts 1 << rot_shift ticks of the 100 MHz clock
 OUT_UNSAT, OUT_FIRST = "%[unsat]", "%[first]"
 
 
@@ -547,8 +552,37 @@ def build():
     a.e("s_cbranch_scc0 .Lzk_next")  # NOP and anything unknown
     # BARRIER: everything this wavefront stored is visible to the workgroup once its memory
     # operations have completed; then wait for the other strands
+    a.e("s_cmp_eq_u32 %s, -1" % IN_ROT)
+    a.e("s_cbranch_scc0 .Lzk_barrier_turn")
     a.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a.e("s_barrier")
+    a.e("s_branch .Lzk_next")
+    # Priority turns, as in the stream on 29-bit limbs: the workgroups resident on a CU hold four different issue
+    # priorities that turn with the constant-rate clock, each workgroup in its own phase, so that they finish
+    # together instead of in the order they were placed (a SIMD issues from its oldest wavefront first).
+    a.label(".Lzk_barrier_turn")
+    a.e("s_memrealtime %s" % NOW)
+    a.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    a.e("s_barrier")
+    a.e("s_lshr_b32 %s, %s, %s" % (T0, NOW_LO, IN_ROTSH))
+    a.e("s_add_u32 %s, %s, %s" % (T0, T0, IN_ROT))
+    a.e("s_and_b32 %s, %s, 3" % (T0, T0))
+    a.e("s_cmp_lt_u32 %s, 2" % T0)
+    a.e("s_cbranch_scc1 .Lzk_prio01")
+    a.e("s_cmp_eq_u32 %s, 2" % T0)
+    a.e("s_cbranch_scc1 .Lzk_prio2")
+    a.e("s_setprio 3")
+    a.e("s_branch .Lzk_next")
+    a.label(".Lzk_prio2")
+    a.e("s_setprio 2")
+    a.e("s_branch .Lzk_next")
+    a.label(".Lzk_prio01")
+    a.e("s_cmp_eq_u32 %s, 0" % T0)
+    a.e("s_cbranch_scc1 .Lzk_prio0")
+    a.e("s_setprio 1")
+    a.e("s_branch .Lzk_next")
+    a.label(".Lzk_prio0")
+    a.e("s_setprio 0")
     a.e("s_branch .Lzk_next")
 
     def io_descriptor(base, index_reg):
@@ -675,6 +709,7 @@ def build():
     a.e("s_cbranch_scc1 .Lzk_top")
 
     a.label(".Lzk_end")
+    a.e("s_setprio 0")
     a.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a.e("s_mov_b64 %s, %s" % (OUT_UNSAT, UNSAT))
     a.e("v_mov_b32 %s, %s" % (OUT_FIRST, FIRST))

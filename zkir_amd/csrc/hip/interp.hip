@@ -371,7 +371,7 @@ zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, ui
                         uint64_t n_vectors, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ outputs,
                         uint4* __restrict__ gslot_pool, uint32_t gslots_per_block,
                         uint64_t* __restrict__ unsat_per_tape, uint64_t* __restrict__ stats,
-                        uint32_t* __restrict__ work_counter, uint32_t victim_row, uint32_t strands, uint32_t lslots) {
+                        uint32_t* __restrict__ work_counter, uint32_t victim_row, uint32_t strands, uint32_t lslots, uint32_t turns) {
   __shared__ uint32_t next_item;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
   const uint32_t row_sets = strands == 8u ? 2u : 1u, set = wave >> 2;  // which set of slot rows this wavefront uses
@@ -387,6 +387,11 @@ zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, ui
   const uint32_t evict_below = victim_row ? 0x20000000u : 0u;
   const uint32_t v_lo = (wave & 3u) * 2048u + lane * 16u, v_x = lane * 16u;
   const uint32_t n4 = (uint32_t)n_vectors * 4u;
+  // priority turns of a strand tape (turns = CUs | log2 of the turn in clock ticks << 16; 0: none): workgroups are
+  // placed CU by CU in the order of their numbers, so the ones that share a CU are one CU count apart and the
+  // quotient tells them apart
+  const uint32_t rot = turns ? __builtin_amdgcn_readfirstlane(blockIdx.x / (turns & 0xffffu)) : 0xffffffffu;
+  const uint32_t rot_shift = turns >> 16;
 
   const uint64_t total = (uint64_t)n_tapes * passes_per_tape;
   for (;;) {
@@ -417,7 +422,7 @@ zkir_interp_lean_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, ui
                  : [ops] "s"(ops), [n_ops] "s"(n_ops), [consts] "s"(consts), [n_consts] "s"(td.n_consts),
                    [gslots] "s"(gslots), [gslot_bytes] "s"(gslot_bytes), [lds_base] "s"(lds_base),
                    [in_base] "s"(in_base), [out_base] "s"(out_base), [n4] "s"(n4), [live] "s"(live_mask),
-                   [evict_below] "s"(evict_below), [xbase] "s"(xbase), [one_word] "s"(td.one_word), [v_lo] "v"(v_lo), [v_vec4] "v"(v_vec4), [v_x] "v"(v_x)
+                   [evict_below] "s"(evict_below), [xbase] "s"(xbase), [one_word] "s"(td.one_word), [rot] "s"(rot), [rot_shift] "s"(rot_shift), [v_lo] "v"(v_lo), [v_vec4] "v"(v_vec4), [v_x] "v"(v_x)
                  : ZKIR_INTERP_CORE_CLOBBERS);
 
     if (lane == 0 && wave_unsat)
@@ -461,10 +466,7 @@ zkir_interp_lean29_kernel(const TapeDesc* __restrict__ tapes, uint32_t n_tapes, 
   const uint32_t v_lo = (wave & 3u) * kWave29 + lane * 16u, v_lo4 = (wave & 3u) * kWave29 + 2048u + lane * 4u;
   const uint32_t v_x = lane * 16u, v_x4 = 2048u + lane * 4u;
   const uint32_t n4 = (uint32_t)n_vectors * 4u;
-  // priority turns of a strand tape (turns = CUs | log2 of the turn in clock ticks << 16; 0: none): workgroups are
-  // placed CU by CU in the order of their numbers, so the ones that share a CU are one CU count apart and the
-  // quotient tells them apart
-  const uint32_t rot = turns ? __builtin_amdgcn_readfirstlane(blockIdx.x / (turns & 0xffffu)) : 0xffffffffu;
+  const uint32_t rot = turns ? __builtin_amdgcn_readfirstlane(blockIdx.x / (turns & 0xffffu)) : 0xffffffffu;  // as in zkir_interp_lean_kernel
   const uint32_t rot_shift = turns >> 16;
   if (threadIdx.x < 32) {  // entry q: the limbs of q*p, 12 words (9 used)
     uint32_t* row = (uint32_t*)zkir_lds_slots + threadIdx.x * 12;
@@ -694,7 +696,7 @@ hipError_t launch_interp(int variant, const TapeDesc* tapes_dev, uint32_t n_tape
     if (e != hipSuccess) return e;
   }
   uint4* pool = (uint4*)gslot_pool;
-  // the last four are read by the generated-stream kernels only (turns by the 29-bit one)
+  // the last four are read by the generated-stream kernels only
   uint32_t victim_row = interp_victim_row(variant, lslots, strands) ? 1u : 0u;
   // A strand launch with several workgroups per CU: the workgroups take turns at the SIMDs' issue priority (164 us
   // each) instead of running in the order they were placed, the last one finishing alone.
