@@ -54,6 +54,10 @@ extern "C" {
     // a launch's worth of tapes in one copy (campaigns); ids come back in `out[0..n)`
     fn zkir_tape_upload_many(ctx: *mut c_void, n: u32, hdrs: *const TapeHdr, blobs: *const *const c_void,
                              bytes: *const usize, out: *mut u32) -> i32;
+    // the same for tape handles this library lowered (zkir_lower, zkir_generate_lower_many): not validated again
+    fn zkir_tape_upload_handles(ctx: *mut c_void, n: u32, tapes: *const *const c_void, out: *mut u32) -> i32;
+    // thread-seconds the library's host threads have spent generating and lowering since it was loaded
+    fn zkir_host_phase_seconds(generate_s: *mut f64, lower_s: *mut f64) -> i32;
     // zkir_eval_batch on device pointers and a stream; `_noalloc`: the same on the library's fixed scratch
     // array (no hipMalloc in the call: for hosts that run under HIP graph capture)
     fn zkir_eval_batch_dev(ctx: *mut c_void, tape: u32, inputs_soa_dev: *const u32, n: u64, outputs_soa_dev: *mut u32,
@@ -64,6 +68,16 @@ extern "C" {
                        per_tape_unsat: *mut u64) -> i32;
     fn zkir_eval_batch(ctx: *mut c_void, tape: u32, inputs_soa: *const u32, n: u64, outputs_soa: *mut u32,
                        unsat_count: *mut u64, first_unsat: *mut u32) -> i32;
+    // many tapes, one launch, device buffers; per_tape_faults_dev (may be null) names the circuit that divided by zero
+    fn zkir_eval_multi_dev_faults(ctx: *mut c_void, tapes: *const u32, n_tapes: u32, inputs_dev: *const u32, n_per_tape: u64,
+                                  per_tape_unsat_dev: *mut u64, per_tape_faults_dev: *mut u64, result_dev: *mut u64,
+                                  stream: *mut c_void) -> i32;
+    // the campaign's exchange step for one process that drives several GPUs (RCCL inside): counters summed,
+    // divergent circuit ids united; host memory in and out
+    fn zkir_reducer_create(devices: *const i32, n_devices: u32, n_counters: u32, id_capacity: u32, out: *mut *mut c_void) -> i32;
+    fn zkir_reducer_reduce(r: *mut c_void, counters: *const u64, ids: *const u32, n_ids: *const u32, totals: *mut u64,
+                           all_ids: *mut u32, n_all_ids: *mut u32) -> i32;
+    fn zkir_reducer_destroy(r: *mut c_void) -> i32;
 }
 
 /// Why `lower` refused a circuit (ZKIR_LOWER_* of the header); circom is expected to refuse the
