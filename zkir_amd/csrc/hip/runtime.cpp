@@ -283,7 +283,7 @@ struct Plan {
   uint32_t strands = 0, passes = 0, grid = 0;
 };
 
-// pool_rows_cap: 0, or the slot rows (8 KiB each) the caller's fixed pool holds; the grid shrinks to fit
+// pool_rows_cap: 0, or the slot rows (of 9 KiB, the larger of the two streams' rows) the caller's fixed pool holds; the grid shrinks to fit
 int32_t plan_group(zkir_ctx* ctx, const Group& G, int kind, uint64_t N, size_t pool_rows_cap, Plan* P) {
   P->strands = strands_of_kind(kind);
   P->variant = pick_variant(G.full, N, G.max_gslots);
@@ -375,7 +375,7 @@ int32_t launch_group(zkir_ctx* ctx, const Group& G, const Plan& P, const TapeDes
 // One tape on device buffers.  unsat_dev points at the caller's four result words {unsat, packed first unsat,
 // faults, spare} (stats_dev at the second), which this call initialises on the stream.  The tape's own descriptor (written at upload) is used, so nothing is
 // copied.  fixed_scratch: null (the context's growable pool and counters) or a fixed region of
-// `fixed_bytes` whose first 8 KiB hold the work counter and the rest slot rows; with it the call
+// `fixed_bytes` whose first 9 KiB hold the work counter and the rest slot rows; with it the call
 // allocates nothing.
 int32_t run_one(zkir_ctx* ctx, const DevTape& t, const uint32_t* in_dev, uint64_t N, uint32_t* out_dev, uint64_t* unsat_dev,
                 uint64_t* stats_dev, hipStream_t stream, unsigned char* fixed_scratch, size_t fixed_bytes) {
