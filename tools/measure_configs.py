@@ -28,6 +28,7 @@ def main():
     options = z.default_lower_options()
     options.reorder = int(os.environ.get("ZKIR_MEASURE_REORDER", "1"))
     options.scaled_values = int(os.environ.get("ZKIR_MEASURE_SCALED", str(options.scaled_values)))
+    options.n_lslots = int(os.environ.get("ZKIR_MEASURE_LSLOTS", str(options.n_lslots)))  # window rows (0: lower's choice)
     tapes = [t for _, cls, t in campaign.lower_parallel(range(n_circuits), 7, workers=16, lower_options=options) if t is not None]
     # longest tapes first: the work queue hands items out in order, so the tail is made of short ones
     tapes.sort(key=lambda t: -t.hdr.n_ops)
@@ -55,7 +56,8 @@ def main():
     print(json.dumps({"config": "3: %d distinct circuits (%d lowered OK, %d..%d constraints) x %d vectors" % (
         n_circuits, len(tapes), min(t.hdr.n_constraints for t in tapes), max(t.hdr.n_constraints for t in tapes), n_vec),
         "gpu_ms": 1e3 * dt, "checks_per_s": checks / dt, "fr_mul_per_s": muls / dt, "unsat": int(unsat.sum()),
-        "host_generate_lower_s_16_threads": host_s, "reorder": options.reorder, "scaled_values": options.scaled_values,
+        "host_generate_lower_s_16_threads": host_s, "reorder": options.reorder, "scaled_values": options.scaled_values, "window_rows": max(t.hdr.n_lslots for t in tapes),
+        "device_slots_max": max(t.hdr.n_gslots for t in tapes),
         "scaling_products": sum(t.hdr.n_scale_ops for t in tapes),
         "mulhi_frac": 128.0 * muls / dt / ctx.int_mul_rate(0)}))
 
