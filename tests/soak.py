@@ -9,7 +9,7 @@ from oracle import fr_ref as F
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 ctx = z.Context(0)
-rnd = random.Random(20240611)
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20240611)  # python tests/soak.py [iterations [seed]]
 special = [0, 1, 2, F.P - 1, F.P - 2, F.HALF, F.HALF + 1, (1 << 64) - 1, 1 << 253, 253, 254, 255, F.P - 253, F.P - 254]
 done = rejected = bad = full = multi = stranded = scaled = 0
 group = []

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   }
   zkir_lower_options o;
   zkir_lower_options_default(&o);
-  o.reorder = o.order_ops = o.window_cache = 0;  // as a campaign lowers (zkir_amd/campaign.py::campaign_lower_options)
+  o.reorder = o.order_ops = o.window_cache = o.scaled_values = 0;  // as a campaign lowers (zkir_amd/campaign.py::campaign_lower_options)
   const bool only_many = argc > 3;  // a third argument: time only zkir_generate_lower_many
   double t0 = now();
   std::vector<zkir_circuit*> cs(only_many ? 0 : n);
