@@ -35,8 +35,12 @@ const Rccl& rccl() {
   static const Rccl r = [] {
     Rccl x;
     void* h = nullptr;
+    // a copy the process already holds first (a host that imported PyTorch has its wheel's RCCL, bound to the same
+    // HIP runtime this library is bound to), then the system's
     for (const char* name : {"librccl.so.1", "librccl.so"})
-      if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+      if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (!h) return x;
     x.CommInitAll = (decltype(x.CommInitAll))dlsym(h, "ncclCommInitAll");
     x.CommDestroy = (decltype(x.CommDestroy))dlsym(h, "ncclCommDestroy");
