@@ -569,7 +569,7 @@ __global__ void zkir_consts_to_mont29_kernel(const uint32_t* __restrict__ src, u
 // other values on the graph's second replay (ROCm 7.2), a kernel node replays with the arguments it was recorded with.
 __global__ void zkir_init_launch_kernel(uint64_t* result, uint32_t* counters) {
   if (threadIdx.x < 4 && result) result[threadIdx.x] = threadIdx.x == 1 ? ~0ull : 0ull;
-  if (threadIdx.x < 64) counters[threadIdx.x] = 0;
+  if (threadIdx.x < 64 && counters) counters[threadIdx.x] = 0;
 }
 
 // constants arrive canonical; rewrite them in Montgomery form in place

@@ -379,8 +379,9 @@ int32_t launch_group(zkir_ctx* ctx, const Group& G, const Plan& P, const TapeDes
 // allocates nothing.
 int32_t run_one(zkir_ctx* ctx, const DevTape& t, const uint32_t* in_dev, uint64_t N, uint32_t* out_dev, uint64_t* unsat_dev,
                 uint64_t* stats_dev, hipStream_t stream, unsigned char* fixed_scratch, size_t fixed_bytes) {
-  if (N == 0) {  // nothing to launch: the result words still start from {0, all ones, 0, 0}
-    HIP_TRY(ctx, zkir::launch_init(unsat_dev, (uint32_t*)ctx->work_counter, stream));
+  if (N == 0) {  // nothing to launch: the result words still start from {0, all ones, 0, 0}; the work counters are
+                 // left alone (an earlier launch of this context on another stream may be drawing from them)
+    HIP_TRY(ctx, zkir::launch_init(unsat_dev, nullptr, stream));
     return ZKIR_OK;
   }
   if (N >= (1ull << 32)) return fail(ctx, ZKIR_E_LIMIT, "N must be below 2^32");
@@ -706,9 +707,10 @@ static int32_t upload_impl(zkir_ctx* ctx, uint32_t n, const zkir_tape_hdr* hdrs,
     std::vector<std::thread> pool;
     const uint32_t per = (n + n_threads - 1) / n_threads;
     try {
+      pool.reserve(n_threads);
       for (uint32_t t = 1; t < n_threads; t++)
         if (t * per < n) pool.emplace_back(gather, t * per, std::min(n, (t + 1) * per));
-    } catch (const std::system_error&) {  // fewer helpers than asked for: the rest is done here
+    } catch (const std::exception&) {  // fewer helpers than asked for (thread limit, memory): the rest is done here
     }
     const uint32_t started = (uint32_t)pool.size();
     gather(0, std::min(n, per));
