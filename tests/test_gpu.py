@@ -427,15 +427,24 @@ def test_gadget_chain(ctx):
     assert z.unpack_outputs(out[:, :, 7:8])[0] == it.outputs
 
 
-def test_device_pointer_entry_point_full_size(ctx):
-    """The ~1k-constraint circuit over 2^20 vectors on device buffers: no constraint
-    fails, sampled vectors match the checker, and permuting the batch permutes the outputs."""
+@pytest.mark.parametrize("signal_factors", [1, 0])
+def test_device_pointer_entry_point_full_size(ctx, signal_factors):
+    """The ~1k-constraint circuits of the benchmark (both factors of a constraint signals; a factor a constant one
+    time in four, which lower turns into a tape of scaled values) over 2^20 vectors on device buffers: no constraint
+    fails, sampled vectors match the checker on this tape and on the same circuit lowered plainly in program order,
+    and permuting the batch permutes the outputs."""
     torch = pytest.importorskip("torch")
     cfg = dict(min_instructions=4200, max_instructions=4200, forced_inputs=16, inputs_readable=1, arithmetic_only=1,
-               quadratic_aware=1, no_loops=1, safe_array_index=1)
-    tape = z.Lowerer(z.Generator(2024, ext_config(**cfg)).generate()).lower()
+               quadratic_aware=1, no_loops=1, safe_array_index=1, signal_factors=signal_factors, max_linear_terms=1)
+    circuit = z.Generator(2024, ext_config(**cfg)).generate()
+    tape = z.Lowerer(circuit).lower()
     h = tape.hdr
     assert 900 <= h.n_constraints <= 1200
+    assert (h.n_scale_ops > 0) == (signal_factors == 0)  # the cost rule keeps scaled values only where they pay
+    plain_options = z.default_lower_options()
+    plain_options.reorder = plain_options.window_cache = plain_options.order_ops = plain_options.scaled_values = 0
+    plain = z.Lowerer(circuit, plain_options).lower()
+    assert plain.hdr.n_scale_ops == 0 and plain.hdr.n_outputs == h.n_outputs
     n = 1 << 20
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev)
@@ -456,6 +465,8 @@ def test_device_pointer_entry_point_full_size(ctx):
     out_s = out[:, :, idx].cpu().numpy().view(np.uint32)
     o_c, u_c, _, _ = C.eval_cpu(bytes(h), tape.blob(), np.ascontiguousarray(inp_s), len(idx), h.n_outputs)
     assert np.array_equal(np.ascontiguousarray(out_s), o_c) and u_c == 0
+    o_p, u_p, _, _ = C.eval_cpu(bytes(plain.hdr), plain.blob(), np.ascontiguousarray(inp_s), len(idx), h.n_outputs)
+    assert np.array_equal(o_p, o_c) and u_p == 0
     # order of the batch does not matter: reverse the vectors, outputs come out reversed
     inp_r = torch.flip(inp, dims=[2]).contiguous()
     out_r = torch.empty_like(out)
