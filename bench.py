@@ -133,6 +133,9 @@ def self_launch(args):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus))
+    # RCCL shares device memory between the ranks' processes; the host driver of these machines only supports dmabuf
+    # IPC, and with the legacy mode RCCL's set-up fails (hipIpcGetMemHandle: invalid argument).  A value the caller
+    # has set is kept.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = []
     for r in range(args.gpus):
