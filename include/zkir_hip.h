@@ -348,9 +348,9 @@ int32_t zkir_generate_lower_many(const uint64_t* seeds, const zkir_generator_con
                                  int32_t* status_classes);
 
 /* Thread-seconds zkir_generate_lower_many has spent so far, over all its calls and worker threads of this
- * process, generating circuits and lowering them (for circuits whose statements go to lower as they are drawn,
- * without the circuit being built: drawing plus the pass that makes single-assignment ops, and slot placement) (a campaign's report of where its host time goes; the
- * reference has no timing code: src/main.rs:81-92). */
+ * process: *generate_s in drawing circuits (for circuits lowered while they are drawn: drawing plus the pass that
+ * makes single-assignment ops), *lower_s in the rest of lowering (slot placement).  For a campaign's report of
+ * where its host time goes; the reference has no timing code (src/main.rs:81-92). */
 int32_t zkir_host_phase_seconds(double* generate_s, double* lower_s);
 
 int32_t zkir_tape_header(const zkir_tape* t, zkir_tape_hdr* hdr);
@@ -419,8 +419,8 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
  * All contexts of one GPU share the array (two processes do not: each has its own copy): a call that
  * arrives while ANOTHER context's no-alloc launch is still running on that GPU is refused with ZKIR_E_BUSY
  * instead of racing with it; calls of one context are chained like every other launch of it.
- * Under graph capture (the stream is being recorded into a HIP graph) the call records its memsets and its
- * kernel and nothing else: it neither waits for nor records the context's events, and the busy check is
+ * Under graph capture (the stream is being recorded into a HIP graph) the call records its two kernels (one
+ * that initialises the result words and the work counter, then the interpreter) and nothing else: it neither waits for nor records the context's events, and the busy check is
  * skipped.  The caller then synchronises with its tape uploads before the capture begins, and keeps replays
  * of the graph from overlapping any other launch that uses the same context or the same GPU's array. */
 #define ZKIR_NOALLOC_SCRATCH_BYTES (64u << 20)
