@@ -8,6 +8,7 @@ from oracle import c_oracle as C
 from oracle import fr_ref as F
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+BIG = os.environ.get("SOAK_BIG") == "1"  # circuits of the benchmark's size and beyond: tapes that spill heavily
 ctx = z.Context(0)
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20240611)  # python tests/soak.py [iterations [seed]]
 special = [0, 1, 2, F.P - 1, F.P - 2, F.HALF, F.HALF + 1, (1 << 64) - 1, 1 << 253, 253, 254, 255, F.P - 253, F.P - 254]
@@ -16,7 +17,7 @@ group = []
 t0 = time.time()
 for it in range(N):
     g = z.default_generator_config()
-    n = rnd.choice([20, 40, 80, 160, 320, 640])
+    n = rnd.choice([320, 640, 1280, 2560, 5120] if BIG else [20, 40, 80, 160, 320, 640])
     g.min_instructions = g.max_instructions = n
     g.max_expr_depth = rnd.choice([1, 1, 2, 3])
     g.inputs_readable = 1
