@@ -63,7 +63,7 @@ def timeit(ctx, tape, label, want_outputs=True, n=1 << 20, steps=5):
     ctx.release(tid)
 
 
-os.environ["ZKIR_INTERP"] = "lean32"  # the altered tapes keep few device slots: hold the kernel fixed
+os.environ["ZKIR_INTERP"] = os.environ.get("ZKIR_BREAKDOWN_KERNEL", "lean32")  # the altered tapes keep few device slots: hold the kernel fixed
 ctx = z.Context(0)
 t = bench.workload_tape(z)
 for rep in range(2):
