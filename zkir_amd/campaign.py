@@ -312,8 +312,10 @@ def main(argv=None):
     ap.add_argument("--circuits", type=int, default=1024)
     ap.add_argument("--vectors", type=int, default=1024, help="input vectors per circuit")
     ap.add_argument("--seed", type=int, default=7)
-    ap.add_argument("--group", type=int, default=2048,
-                    help="circuits per launch (a launch should hold several times the 1 280 workgroups the GPU runs at once)")
+    ap.add_argument("--group", type=int, default=512,
+                    help="circuits per launch: a launch should hold several times the 1 280 workgroups the GPU runs at once "
+                         "(512 circuits x 1 024 vectors are 2 048), and small launches keep the host's lowering and the GPU's "
+                         "evaluation overlapped (measured end to end on one GPU: 512 -> 11 400 circuits/s, 2 048 -> 9 700)")
     ap.add_argument("--workers", type=int, default=8, help="host threads that generate and lower, per rank")
     ap.add_argument("--strands", type=int, default=0, choices=[0, 4, 8],
                     help="4: ask lower for strand tapes (circuits they do not fit come back as plain tapes); for "
