@@ -347,7 +347,14 @@ def main():
             n_circ, n_vec = (64 if dry else args.campaign_circuits if args.campaign_circuits > 0 else 12500 * world), (16 if dry else 1024)
             ids = campaign.shard(n_circ, rank, world)
             # the ranks of this job share one host (one node): every rank takes its share of the host's threads
-            workers = max(1, min(8, host_threads() // max(1, world)))
+            # (at least 4 where the machine has the CPUs: OMP_NUM_THREADS, which host_threads() honours, may hold one
+            # GPU's share of the host rather than the job's)
+            try:
+                allowed = len(os.sched_getaffinity(0))
+            except AttributeError:
+                allowed = os.cpu_count() or 1
+            budget = max(host_threads() // max(1, world), min(4, allowed // max(1, world)))
+            workers = max(1, min(int(os.environ.get("ZKIR_CAMPAIGN_WORKERS", "16")), budget))
             if dry:
                 def evaluator(tapes, n_vectors, circuit_ids):  # no GPU: the lowering and the exchange still run
                     return [0] * len(tapes), 0
@@ -358,7 +365,7 @@ def main():
             t0 = time.perf_counter()
             # a launch per batch the host hands over: the GPU has time to spare, and what is left to evaluate when the
             # host has finished is one small launch
-            res_c = campaign.run_local(ids, 7, n_vec, evaluator, group=int(os.environ.get("ZKIR_CAMPAIGN_GROUP", "512")),
+            res_c = campaign.run_local(ids, 7, n_vec, evaluator, group=int(os.environ.get("ZKIR_CAMPAIGN_GROUP", "1024")),
                                        lowered=campaign.lower_parallel(ids, 7, workers=workers, stats=host_stats))
             t_red = time.perf_counter()
             tot = campaign.reduce_results(res_c, dist if world > 1 else None, device if not rehearse else None)
@@ -382,7 +389,9 @@ def main():
                          "host_threads_per_rank": workers,
                          # rank 0's seconds per phase: generate and lower are thread-seconds over its workers (they run
                          # beside the evaluation on a helper thread, generate_lower_wall_s being that thread's wall clock);
-                         # upload, inputs (drawing the vectors), evaluate and release are the evaluating thread's wall clock
+                         # upload, inputs (sending the vector draws and the launch), wait (blocked on a group's results)
+                         # and release are the evaluating thread's wall clock; evaluate is the GPU's own time over the
+                         # groups (HIP events), which runs behind the upload of the next group
                          "phases_rank0": phases})
 
     if rank == 0:

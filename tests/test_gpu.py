@@ -664,6 +664,73 @@ def test_two_streams_one_context_give_serial_results(ctx):
         ctx.release(t)
 
 
+def test_release_while_later_launches_run(ctx):
+    """A pipelined caller releases the tapes of a launch while the next launches are still running (on a stream of its
+    own) and uploads new tapes into the space: the release waits for the launch that read the tape, not for the
+    device, and nothing a running launch reads is touched.  Results equal those of the same work done serially."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    cfg = dict(forced_inputs=6, inputs_readable=1, arithmetic_only=1, quadratic_aware=1, no_loops=1, safe_array_index=1)
+    groups = [[z.Lowerer(z.Generator(700 + 10 * g + k, ext_config(min_instructions=400 + 100 * k, max_instructions=400 + 100 * k, **cfg)).generate()).lower()
+               for k in range(6)] for g in range(12)]  # more groups than the runtime keeps launch events for
+    n = 4096
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(33)
+    inputs = []
+    for tapes in groups:
+        a = torch.randint(0, 1 << 32, (sum(t.hdr.n_inputs for t in tapes), 8, n), dtype=torch.int64, device=dev, generator=gen).to(torch.int32)
+        a[:, 7, :] &= 0x0FFFFFFF
+        inputs.append(a)
+    # plant a failure in one tape of every group, so that the counts differ from group to group
+    for g, tapes in enumerate(groups):
+        ops = [list(op) for op in tapes[g % 6].ops()]
+        j = [i for i, op in enumerate(ops) if op[0] & 0xFF == F.OP_CHECK][g]
+        ops[j][1] = F.operand(F.K_CONST, 0)  # the product is compared with the pool's first constant
+        tapes[g % 6] = z.Tape.from_parts(tapes[g % 6].hdr, b"".join(struct.pack("<4I", *op) for op in ops) + tapes[g % 6].blob()[16 * len(ops):])
+
+    def serial():
+        out = []
+        for tapes, inp in zip(groups, inputs):
+            ids = ctx.upload_many(tapes)
+            u = torch.zeros(len(tapes), dtype=torch.int64, device=dev)
+            ctx.eval_multi_dev(ids, inp.data_ptr(), n, u.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            out.append(u.cpu())
+            for i in ids:
+                ctx.release(i)
+        return out
+
+    def pipelined():
+        side = torch.cuda.Stream()
+        out, prev = [], None
+        for tapes, inp in zip(groups, inputs):
+            ids = ctx.upload_many(tapes)  # while the last group's launch runs
+            u = torch.zeros(len(tapes), dtype=torch.int64, device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            ctx.eval_multi_dev(ids, inp.data_ptr(), n, u.data_ptr(), side.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(side)
+            if prev is not None:  # the last group: wait for ITS launch only, read, release while this group's launch runs
+                pids, pu, pdone = prev
+                pdone.synchronize()
+                out.append(pu.cpu())
+                for i in pids:
+                    ctx.release(i)
+            prev = (ids, u, done)
+        pids, pu, pdone = prev
+        pdone.synchronize()
+        out.append(pu.cpu())
+        for i in pids:
+            ctx.release(i)
+        return out
+
+    want = serial()
+    assert all(int(u.sum()) > 0 for u in want)
+    for _ in range(2):
+        got = pipelined()
+        assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+
+
 def test_run_time_faults_of_a_multi_tape_launch_reach_the_caller(ctx):
     """Division by a run-time zero in some vectors of some tapes of one device-pointer launch: the fault
     count comes back in the caller's result words (and through the campaign's evaluator)."""

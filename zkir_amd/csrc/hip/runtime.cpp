@@ -47,6 +47,7 @@ struct DevTape {
   void* desc = nullptr;    // device: the TapeDesc of this tape evaluated alone (offsets 0, unsat index 0)
   uint32_t one_word = 0xffffffffu;  // operand word of the constant 1 in the tape's pool, if it holds one
   int slab = -1;           // which slab of the context's tape arena holds ops, consts and desc
+  uint64_t last_launch = 0;  // number of the latest chained launch that reads this tape (0: none yet)
 };
 
 // Device memory for uploaded tapes: slabs with bump allocation, so that an upload costs one
@@ -89,7 +90,14 @@ struct zkir_ctx {
   bool launched_since_sync = false;  // a launch may still be reading tapes: release must wait for the device
   // Launches of one context share its work counters, descriptor buffer and slot pool, so they run one
   // after the other whatever streams the caller uses: every launch waits for launch_done of the one before.
-  hipEvent_t launch_done = nullptr;
+  // The events of the last kLaunchRing launches are kept (launch number n uses entry (n - 1) % kLaunchRing), so that
+  // releasing a tape waits for the launch that read it and not for whatever was launched since.
+  static constexpr int kLaunchRing = 8;
+  hipEvent_t launch_ev[kLaunchRing] = {};
+  uint64_t launch_seq = 0;    // chained launches recorded so far
+  uint64_t done_seq = 0;      // launches known to have finished (chained launches finish in order)
+  bool unchained = false;     // a launch went out without an event (ZKIR_NO_CHAIN, graph capture): only a device
+                              // synchronisation says when it is over
   bool launch_recorded = false;
   // descriptors of a multi-tape call travel through pinned host memory the context owns (two buffers in
   // turn; a buffer is rewritten only after the copy that read it has finished)
@@ -341,25 +349,34 @@ int32_t chain_stream(zkir_ctx* ctx, hipStream_t stream) {
   if (ctx->upload_pending) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->upload_done, 0));
   static const bool off = std::getenv("ZKIR_NO_CHAIN") != nullptr;  // measurement aid: the caller keeps to one stream
   if (off) return ZKIR_OK;
-  if (ctx->launch_recorded) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->launch_done, 0));
+  if (ctx->launch_recorded) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->launch_ev[(ctx->launch_seq - 1) % zkir_ctx::kLaunchRing], 0));
   return ZKIR_OK;
 }
 int32_t chain_done(zkir_ctx* ctx, hipStream_t stream) {
   static const bool off = std::getenv("ZKIR_NO_CHAIN") != nullptr;
   if (off || stream_is_capturing(stream)) {
     ctx->launched_since_sync = true;
+    ctx->unchained = true;
     return ZKIR_OK;
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->launch_done, stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->launch_ev[ctx->launch_seq % zkir_ctx::kLaunchRing], stream));
+  ctx->launch_seq++;
   ctx->launch_recorded = true;
   ctx->launched_since_sync = true;
   return ZKIR_OK;
+}
+bool make_launch_events(zkir_ctx* ctx) {
+  for (hipEvent_t& ev : ctx->launch_ev)
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+  return true;
 }
 // the device has been synchronised: nothing is in flight any more
 void note_device_idle(zkir_ctx* ctx) {
   ctx->upload_pending = false;
   ctx->launched_since_sync = false;
   ctx->launch_recorded = false;
+  ctx->unchained = false;
+  ctx->done_seq = ctx->launch_seq;
 }
 
 int32_t launch_group(zkir_ctx* ctx, const Group& G, const Plan& P, const TapeDesc* descs_dev, const uint32_t* in_dev, uint64_t N,
@@ -492,7 +509,10 @@ int32_t run_tapes(zkir_ctx* ctx, const zkir_tape_id* ids, uint32_t n, const uint
     ctx->launched_since_sync = true;
     desc_at += G[k].count;
   }
-  return chain_done(ctx, stream);
+  rc = chain_done(ctx, stream);
+  if (rc) return rc;
+  for (uint32_t i = 0; i < n; i++) ctx->tapes[ids[i]].last_launch = ctx->launch_seq;
+  return ZKIR_OK;
 }
 
 }  // namespace
@@ -536,12 +556,13 @@ int32_t zkir_ctx_create(int32_t device, zkir_ctx** out) {
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->result_buf, 4 * sizeof(uint64_t)) != hipSuccess ||
       hipMalloc(&ctx->work_counter, 256) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->upload_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->launch_done, hipEventDisableTiming) != hipSuccess ||
+      !make_launch_events(ctx) ||
       hipGetSymbolAddress((void**)&ctx->static_scratch, HIP_SYMBOL(scratch)) != hipSuccess || !ctx->static_scratch) {
     if (ctx->result_buf) (void)hipFree(ctx->result_buf);
     if (ctx->work_counter) (void)hipFree(ctx->work_counter);
     if (ctx->upload_done) (void)hipEventDestroy(ctx->upload_done);
-    if (ctx->launch_done) (void)hipEventDestroy(ctx->launch_done);
+    for (hipEvent_t ev : ctx->launch_ev)
+      if (ev) (void)hipEventDestroy(ev);
     delete ctx;
     return ZKIR_E_HIP;
   }
@@ -559,7 +580,8 @@ int32_t zkir_ctx_destroy(zkir_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (TapeSlab& sl : ctx->slabs) (void)hipFree(sl.base);
   if (ctx->upload_done) (void)hipEventDestroy(ctx->upload_done);
-  if (ctx->launch_done) (void)hipEventDestroy(ctx->launch_done);
+  for (hipEvent_t ev : ctx->launch_ev)
+    if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : ctx->desc_copied)
     if (ev) (void)hipEventDestroy(ev);
   for (void* b : ctx->desc_stage)
@@ -751,8 +773,17 @@ int32_t zkir_tape_release(zkir_ctx* ctx, zkir_tape_id id) {
   if (it == ctx->tapes.end()) return fail(ctx, ZKIR_E_INVALID, "unknown tape id");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->launched_since_sync) {  // no launch may still be reading the tape
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    note_device_idle(ctx);
+    const uint64_t used = it->second.last_launch;
+    if (!ctx->unchained && used <= ctx->done_seq) {
+      // never launched, or its last launch is known to be over
+    } else if (!ctx->unchained && ctx->launch_seq - used < (uint64_t)zkir_ctx::kLaunchRing) {
+      // wait for the launch that read it: launches sent since (the next group of a pipelined caller) keep running
+      HIP_TRY(ctx, hipEventSynchronize(ctx->launch_ev[(used - 1) % zkir_ctx::kLaunchRing]));
+      ctx->done_seq = std::max(ctx->done_seq, used);
+    } else {
+      HIP_TRY(ctx, hipDeviceSynchronize());
+      note_device_idle(ctx);
+    }
   }
   ctx->slabs[it->second.slab].live--;
   ctx->tapes.erase(it);
@@ -767,7 +798,9 @@ int32_t zkir_eval_batch_dev(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* in
   if (it->second.hdr.n_inputs && N && !inputs_soa_dev) return fail(ctx, ZKIR_E_INVALID, "inputs required");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
-  return run_one(ctx, it->second, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s, nullptr, 0);
+  const int32_t rc = run_one(ctx, it->second, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s, nullptr, 0);
+  if (rc == ZKIR_OK && N) it->second.last_launch = ctx->launch_seq;
+  return rc;
 }
 
 int32_t zkir_eval_batch_dev_noalloc(zkir_ctx* ctx, zkir_tape_id tape, const uint32_t* inputs_soa_dev, uint64_t N,
@@ -789,6 +822,7 @@ int32_t zkir_eval_batch_dev_noalloc(zkir_ctx* ctx, zkir_tape_id tape, const uint
   // the result words and the counter are initialised by run_one; slot rows need no clearing (a tape writes a slot before it reads it)
   const int32_t rc = run_one(ctx, it->second, inputs_soa_dev, N, outputs_soa_dev, result_dev, result_dev + 1, s, ctx->static_scratch,
                              (size_t)ZKIR_NOALLOC_SCRATCH_BYTES);
+  if (rc == ZKIR_OK && N) it->second.last_launch = ctx->launch_seq;
   if (rc == ZKIR_OK && owner && !capturing && owner->done) {
     if (hipEventRecord(owner->done, s) == hipSuccess) {
       owner->ctx = ctx;
