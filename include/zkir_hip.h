@@ -374,6 +374,10 @@ const char* zkir_last_error(const zkir_ctx* ctx);
 /* Validate and copy a tape to the device; constants are converted to
  * Montgomery form on the device. */
 int32_t zkir_tape_upload(zkir_ctx* ctx, const zkir_tape_hdr* hdr, const void* blob, size_t bytes, zkir_tape_id* out);
+/* Give a tape's device memory back.  If a launch that reads the tape may still be running the call waits for
+ * THAT launch (the context keeps the events of its last eight launches), not for the device: a caller that works
+ * one launch ahead releases the tapes of launch k while launch k + 1 runs.  (After launches made under graph
+ * capture or with ZKIR_NO_CHAIN in the environment it waits for the device.) */
 int32_t zkir_tape_release(zkir_ctx* ctx, zkir_tape_id id);
 
 /* zkir_tape_upload for n tapes at once: one device allocation, one copy and one
