@@ -253,8 +253,8 @@ class GpuEvaluator:
     returns a handle, result() of the handle waits for it, reads the counters back and releases the tapes."""
 
     class _Pending:
-        def __init__(self, owner, tids, keep, unsat, faults, result, begin, end):
-            self.owner, self.tids, self.keep = owner, tids, keep
+        def __init__(self, owner, tids, keep, unsat, faults, result, begin, end, order):
+            self.owner, self.tids, self.keep, self.order = owner, tids, keep, order
             self.unsat, self.faults, self.result_words, self.begin, self.end = unsat, faults, result, begin, end
 
         def result(self):
@@ -263,8 +263,11 @@ class GpuEvaluator:
             t0 = time.perf_counter()
             self.end.synchronize()
             t1 = time.perf_counter()
-            out = [int(v) for v in self.unsat.cpu()], [int(v) for v in self.faults.cpu()]
-            assert sum(out[1]) == int(self.result_words[2].item())
+            sorted_out = [int(v) for v in self.unsat.cpu()], [int(v) for v in self.faults.cpu()]
+            assert sum(sorted_out[1]) == int(self.result_words[2].item())
+            out = [0] * len(self.order), [0] * len(self.order)  # back in the order the caller gave the tapes in
+            for at, k in enumerate(self.order):
+                out[0][k], out[1][k] = sorted_out[0][at], sorted_out[1][at]
             for tid in self.tids:
                 o.ctx.release(tid)
             self.keep = None
@@ -289,6 +292,9 @@ class GpuEvaluator:
         import time
         torch = self.torch
         t0 = time.perf_counter()
+        # longest tapes first: workgroups draw (tape, pass) items in order, so the launch's tail is made of short ones
+        order = sorted(range(len(tapes)), key=lambda k: -tapes[k].hdr.n_ops)
+        tapes = [tapes[k] for k in order]
         tids = self.ctx.upload_many(tapes)
         t1 = time.perf_counter()
         with torch.cuda.stream(self.stream):
@@ -305,7 +311,7 @@ class GpuEvaluator:
         t2 = time.perf_counter()
         self.seconds["upload_s"] += t1 - t0
         self.seconds["inputs_s"] += t2 - t1
-        return GpuEvaluator._Pending(self, tids, inp, unsat, faults, result, begin, end)
+        return GpuEvaluator._Pending(self, tids, inp, unsat, faults, result, begin, end, order)
 
     def __call__(self, tapes, n_vectors, circuit_ids):
         return self.submit(tapes, n_vectors, circuit_ids).result()
