@@ -727,8 +727,14 @@ def test_release_while_later_launches_run(ctx):
     want = serial()
     assert all(int(u.sum()) > 0 for u in want)
     for _ in range(2):
+        # a tape launched before all of them and released after: its launch is older than the events the runtime keeps
+        first = ctx.upload(groups[0][0])
+        u0 = torch.zeros(1, dtype=torch.int64, device=dev)
+        ctx.eval_multi_dev([first], inputs[0].data_ptr(), n, u0.data_ptr(), torch.cuda.current_stream().cuda_stream)
         got = pipelined()
+        ctx.release(first)
         assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+        assert int(u0[0]) == int(want[0][0])
 
 
 def test_run_time_faults_of_a_multi_tape_launch_reach_the_caller(ctx):
