@@ -43,6 +43,38 @@ def run_rank(rank, world):
     return res
 
 
+def test_an_evaluator_that_runs_one_group_ahead_gives_the_same_campaign():
+    """run_local hands an evaluator with submit() the next group before it reads the last group's results (what
+    GpuEvaluator does with launches): same totals, same divergent ids, and the calls come in that order."""
+    log = []
+
+    class Ahead:
+        def __call__(self, tapes, n_vectors, ids):
+            raise AssertionError("an evaluator with submit() is driven through it")
+
+        def submit(self, tapes, n_vectors, ids):
+            log.append(("submit", ids[0]))
+            outer = self
+
+            class Handle:
+                def result(self):
+                    log.append(("result", ids[0]))
+                    return oracle_evaluate(tapes, n_vectors, ids)
+            return Handle()
+
+    o = z.default_lower_options()
+    o.max_iterations = 200
+    want = campaign.reduce_results(run_rank(0, 1))
+    got = campaign.reduce_results(campaign.run_local(campaign.shard(N_CIRCUITS, 0, 1), BASE_SEED, N_VECTORS, Ahead(),
+                                                     config_of=small_config, lower_options=o, group=5))
+    assert got == want
+    kinds = [k for k, _ in log]
+    assert kinds[:3] == ["submit", "submit", "result"] and kinds[-1] == "result"
+    assert kinds.count("submit") == kinds.count("result") >= 3
+    # every group's results are read exactly once, in the order the groups were sent
+    assert [i for k, i in log if k == "submit"] == [i for k, i in log if k == "result"]
+
+
 def test_shard_is_a_partition():
     for world in (1, 2, 3, 8):
         got = sorted(i for r in range(world) for i in campaign.shard(37, r, world))
